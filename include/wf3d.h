@@ -1,0 +1,144 @@
+/* wf3d.h — C ABI of libwf3d.so: the MI355X (gfx950) kernels behind the
+ * PointNetEncoder -> VertexPredictor -> EdgePredictor forward/backward path.
+ *
+ * The reference (cansdev/wireframe-3d-prediction) has no FFI/operator layer: its
+ * path is torch.nn modules calling ATen.  Each entry point
+ * below therefore replaces the ATen op sequence of the cited reference lines;
+ * the Python host (wireframe-3d-prediction_amd/wf3d/ops.py) binds them with
+ * ctypes and the drop-in classes in wireframe-3d-prediction_amd/models/ call
+ * them from torch.autograd.Function.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; every pointer is a DEVICE
+ *     pointer borrowed for the call (no ownership taken, nothing allocated).
+ *   - all tensors fp32, row-major, unless a name says otherwise
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     never synchronises, never throws; returns WF3D_OK or a negative code and
+ *     leaves a message for wf3d_last_error() (thread-local).
+ *   - scratch comes from the caller: `ws` of at least the matching
+ *     *_ws_bytes(...) bytes, 256-byte aligned.
+ */
+#ifndef WF3D_H
+#define WF3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF3D_VERSION 100
+
+#define WF3D_OK 0
+#define WF3D_ERR_ARG (-1)
+#define WF3D_ERR_LAUNCH (-2)
+#define WF3D_ERR_WS (-3)
+#define WF3D_ERR_UNSUPPORTED (-4)
+
+/* activations fused into prologues / elementwise kernels */
+#define WF3D_ACT_NONE 0
+#define WF3D_ACT_RELU 1 /* nn.ReLU   — PointNetEncoder.py:38, VertexPredictor.py:30 */
+#define WF3D_ACT_GELU 2 /* nn.GELU (erf) — EdgePredictor.py:34,59,63,66 */
+
+/* GEMM operand layouts (k = reduction index) */
+#define WF3D_NT 0 /* C[M,N] = A[M,K] · B[N,K]^T  — nn.Linear forward  (aten::addmm) */
+#define WF3D_NN 1 /* C[M,N] = A[M,K] · B[K,N]    — Linear dgrad  dX = dY·W           */
+#define WF3D_TN 2 /* C[M,N] = A[K,M]^T · B[K,N]  — Linear wgrad  dW = dY^T·X         */
+
+int wf3d_version(void);
+const char* wf3d_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * wf3d_gemm — fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM with a fused
+ * LayerNorm-affine + activation (+dropout) PROLOGUE on the activation operand
+ * and a bias / residual / accumulate EPILOGUE.
+ *
+ * Replaces, per reference Linear: aten::addmm (+ the native_layer_norm apply,
+ * relu_/gelu and dropout that precede it), e.g. PointNetEncoder.py:35-45,94;
+ * VertexPredictor.py:27-61,105-117; EdgePredictor.py:31-38,56-68,106,137;
+ * and in backward the two mm's autograd derives per Linear.
+ *
+ * Prologue (applied while the operand tile is staged into LDS), on operand A
+ * for WF3D_NT and on operand B for WF3D_TN, over that operand's own [rows, cols]
+ * global shape:   v' = drop( act( (v - mu[row]) * rs[row] * gamma[col] + beta[col] ) )
+ * pro_mu == NULL skips the LayerNorm part (v' = drop(act(v))).
+ * ------------------------------------------------------------------------ */
+typedef struct wf3d_gemm_t {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   /* [N] or NULL                                         */
+    const float* addend; /* [M, ld_addend] added in the epilogue, or NULL       */
+    int M, N, K;
+    int lda, ldb, ldc, ld_addend;
+    int layout;          /* WF3D_NT / WF3D_NN / WF3D_TN                        */
+    int pro_act;         /* WF3D_ACT_*; prologue enabled iff pro_enable != 0    */
+    int pro_enable;
+    const float* pro_mu;    /* [rows] or NULL */
+    const float* pro_rs;    /* [rows]         */
+    const float* pro_gamma; /* [cols] or NULL (NULL with pro_mu == NULL)        */
+    const float* pro_beta;  /* [cols]         */
+    float drop_p;           /* 0 = no dropout; else keep-prob 1-p, scaled 1/(1-p) */
+    uint32_t drop_seed;
+    int accumulate;      /* C += result instead of C = result                   */
+    void* ws;            /* split-K slabs, wf3d_gemm_ws_bytes() bytes, or NULL  */
+    size_t ws_bytes;
+} wf3d_gemm_t;
+
+size_t wf3d_gemm_ws_bytes(int M, int N, int K, int layout);
+int wf3d_gemm(const wf3d_gemm_t* desc, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm pieces (nn.LayerNorm, eps 1e-5, biased variance — SURVEY App. A)
+ * ------------------------------------------------------------------------ */
+/* mu[r], rs[r] = mean, 1/sqrt(var+eps) of row r of z[R, D] (row stride ld).
+ * Replaces the statistics half of aten::native_layer_norm. */
+int wf3d_row_stats(const float* z, int R, int D, int ld, float eps, float* mu, float* rs, void* stream);
+
+/* out[r,c] = drop(act(LN(z)))[r,c] + addend[r,c]  (materialising form, used
+ * where the value has several consumers: VertexPredictor.py:110,114 residual
+ * sums, EdgePredictor.py:106,114).  mu == NULL skips the LayerNorm. */
+int wf3d_ln_act_apply(const float* z, int R, int D, const float* mu, const float* rs,
+                      const float* gamma, const float* beta, int act, const float* addend,
+                      float drop_p, uint32_t drop_seed, float* out, void* stream);
+
+/* Backward of h = drop(act(LN(z))) given dh: writes dz (may alias dh) and the
+ * column reductions dgamma[D], dbeta[D] (LayerNorm affine grads) and
+ * dbias[D] = sum_r dz[r,:] (the preceding Linear's bias grad).  Any of the
+ * three outputs may be NULL.  Replaces native_layer_norm_backward +
+ * threshold_backward / gelu_backward + the bias sum. */
+size_t wf3d_ln_act_bwd_ws_bytes(int R, int D);
+int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, const float* mu, const float* rs,
+                    const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
+                    float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* out[c] = sum_r x[r,c] * (w ? w[r] : 1)   — bias grads of Linears with no LN
+ * behind them, and the distance-weight grad of the split edge layer. */
+size_t wf3d_colsum_ws_bytes(int R, int D);
+int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, float* out, void* ws,
+                size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Pools (PointNetEncoder.py:85-86,103-111 and VertexPredictor.py:86-88)
+ * ------------------------------------------------------------------------ */
+/* valid[m] = (sum_k |x[m,k]| > 1e-9) ? 1 : 0 */
+int wf3d_point_valid(const float* x, int M, int in_dim, float* valid, void* stream);
+
+/* One pass over point_features pf[B,N,C] producing all four reductions the two
+ * heads need: masked max (0 where a cloud has no valid point) + its first-max
+ * index, masked mean over max(count,1), unmasked mean, unmasked max + index,
+ * and cnt[b] = max(#valid, 1). */
+size_t wf3d_pool4_ws_bytes(int B, int N, int C);
+int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N, int C, float* mmax, float* mavg,
+                   float* umean, float* umax, int32_t* arg_m, int32_t* arg_u, float* cnt, void* ws,
+                   size_t ws_bytes, void* stream);
+/* dpf[b,n,c] = valid*dmavg/cnt + dumean/N + [n==arg_m]*dmmax + [n==arg_u]*dumax (+ dpf_direct) */
+int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
+                   const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                   const float* dpf_direct, int B, int N, int C, float* dpf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WF3D_H */

@@ -1,0 +1,414 @@
+// fp32 MFMA GEMM for gfx950 with fused LayerNorm/activation prologue.
+//
+//   C[M,N] = pro(A)·B (+ bias[n]) (+ addend[m,n]) (+ C)
+//
+// One workgroup = 256 threads = 4 wave64; each wave owns TM x TN tiles of
+// 32x32 built from v_mfma_f32_32x32x2_f32 (exact f32 FMA chain, 64 FLOP/clk/SIMD,
+// MI355X_MICROARCH.md "Matrix cores").  K is walked in BK=32 slices that are
+// staged global -> registers -> LDS with a two-stage LDS ring: the global loads
+// of slice t+1 are issued before the MFMAs of slice t and written to the other
+// LDS stage after them (async-STAGE split, cdna_hip_programming.md T14), one
+// barrier per slice.
+//
+// LDS images (per operand, chosen by its global layout so that global reads are
+// always 16-B coalesced and no transposition is ever needed):
+//   KC  k-contiguous operand  [rows][36]   -> one ds_read_b128 per 4 MFMAs;
+//       the 36-float row stride puts the 16 lanes of every ds_read_b128 lane
+//       group on 16 distinct 16-B slots (conflict-free, MI355X_MICROARCH.md §LDS)
+//   RC  row-contiguous operand [32][rows]  -> four ds_read_b32 (lanes read
+//       consecutive rows: conflict-free)
+// Both images deliver k = 8*ks + 4*(lane>>5) + j to MFMA j of k-step ks, so any
+// A image pairs with any B image.
+//
+// The LayerNorm-apply + ReLU/GELU (+dropout) of the *previous* layer is fused
+// into the staging pass of the activation operand, so normalised activations
+// are never written to HBM: only pre-LN z and per-row (mu, rstd) exist.
+#include "wf3d_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* addend;
+    int M, N, K, lda, ldb, ldc, ld_addend;
+    const float* pmu; const float* prs; const float* pgam; const float* pbet;
+    int has_ln, has_affine;
+    uint32_t drop_seed, drop_thresh; float drop_scale;
+    int accumulate;
+    int ksplit, kt_per_split;
+    float* slab;
+    int vecA, vecB;
+    int nbm, nbn;
+};
+
+// ---- staging: global -> registers ------------------------------------------
+template <int ROWS, bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ base, int ld, int row0, int nrows,
+                                          int k0, int kend, int vec, int tid, f32x4 (&v)[ROWS / 32]) {
+    constexpr int NV = ROWS / 32;
+    if (KC) {
+        const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int grow = row0 + (tid >> 3) + 32 * i;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (grow < nrows && k < kend) {
+                const float* p = base + (size_t)grow * ld + k;
+                if (vec && k + 3 < kend) {
+                    t = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < kend) t[j] = p[j];
+                }
+            }
+            v[i] = t;
+        }
+    } else {
+        constexpr int TPR = ROWS / 4;       // threads per k-row
+        constexpr int KPP = 256 / TPR;      // k-rows per pass
+        const int grow = row0 + (tid % TPR) * 4;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = k0 + tid / TPR + KPP * i;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (k < kend && grow < nrows) {
+                const float* p = base + (size_t)k * ld + grow;
+                if (vec && grow + 3 < nrows) {
+                    t = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (grow + j < nrows) t[j] = p[j];
+                }
+            }
+            v[i] = t;
+        }
+    }
+}
+
+// ---- prologue: v' = drop(act(LN-affine(v))) on in-bounds elements, 0 elsewhere
+template <int ACT>
+__device__ __forceinline__ float pro_one(float v, float mu, float rs, float g, float b, const GemmParams& p,
+                                         uint32_t grow, uint32_t gcol, bool inb) {
+    float y = p.has_ln ? (v - mu) * rs : v;
+    if (p.has_affine) y = y * g + b;
+    y = wf3d_act<ACT>(y);
+    if (p.drop_thresh) y = wf3d_keep(p.drop_seed, grow, gcol, p.drop_thresh) ? y * p.drop_scale : 0.f;
+    return inb ? y : 0.f;
+}
+
+// ---- staging: registers -> LDS ----------------------------------------------
+template <int ROWS, bool KC>
+__device__ __forceinline__ void store_tile(float* lds, int tid, const f32x4 (&v)[ROWS / 32]) {
+    constexpr int NV = ROWS / 32;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<f32x4*>(&lds[((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4]) = v[i];
+    } else {
+        constexpr int TPR = ROWS / 4;
+        constexpr int KPP = 256 / TPR;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<f32x4*>(&lds[(tid / TPR + KPP * i) * ROWS + (tid % TPR) * 4]) = v[i];
+    }
+}
+
+// ---- fragment read: 4 consecutive-k values of one 32-row tile for this lane --
+template <int ROWS, bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int ks, int h) {
+    if (KC) {
+        return *reinterpret_cast<const f32x4*>(&lds[row * LDK + ks * 8 + 4 * h]);
+    } else {
+        f32x4 r;
+        const float* p = &lds[(ks * 8 + 4 * h) * ROWS + row];
+        r[0] = p[0]; r[1] = p[ROWS]; r[2] = p[2 * ROWS]; r[3] = p[3 * ROWS];
+        return r;
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
+    constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
+    constexpr int NVA = BM / 32, NVB = BN / 32;
+    constexpr bool PRO_A = PRO && A_KC;     // NT: activation operand is A [M,K]
+    constexpr bool PRO_B = PRO && !A_KC;    // TN: activation operand is B [K,N]
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware tile order: blocks bid, bid+8, ... share an XCD (round-robin
+    // dispatch); give each XCD a contiguous run of tiles, column tiles fastest,
+    // so the A row-panel of a tile row is fetched into ONE L2 (bijective form,
+    // cdna_hip_programming.md T1).
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * BM, n0 = (vid % p.nbn) * BN;
+
+    const int ktotal = (p.K + BK - 1) / BK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    // loop-invariant prologue parameters
+    float mu_a[NVA], rs_a[NVA];
+    f32x4 gam_b = {1.f, 1.f, 1.f, 1.f}, bet_b = {0.f, 0.f, 0.f, 0.f};
+    if (PRO_A) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int grow = m0 + (tid >> 3) + 32 * i;
+            const bool ok = p.has_ln && grow < p.M;
+            mu_a[i] = ok ? p.pmu[grow] : 0.f;
+            rs_a[i] = ok ? p.prs[grow] : 1.f;
+        }
+    }
+    if (PRO_B && p.has_affine) {
+        const int gcol = n0 + (tid % (BN / 4)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (gcol + j < p.N) { gam_b[j] = p.pgam[gcol + j]; bet_b[j] = p.pbet[gcol + j]; }
+    }
+
+    f32x4 ra[NVA], rb[NVB];
+    auto fetch = [&](int kt) {
+        load_tile<BM, A_KC>(p.A, p.lda, m0, p.M, kt * BK, p.K, p.vecA, tid, ra);
+        load_tile<BN, B_KC>(p.B, p.ldb, n0, p.N, kt * BK, p.K, p.vecB, tid, rb);
+    };
+    auto commit = [&](int kt, int stage) {
+        float* As = smem + stage * (A_SZ + B_SZ);
+        float* Bs = As + A_SZ;
+        if (PRO_A) {
+            const int k = kt * BK + (tid & 7) * 4;
+            f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (p.has_affine) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j < p.K) { g[j] = p.pgam[k + j]; b[j] = p.pbet[k + j]; }
+            }
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int grow = m0 + (tid >> 3) + 32 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ra[i][j] = pro_one<ACT>(ra[i][j], mu_a[i], rs_a[i], g[j], b[j], p, grow, k + j,
+                                            grow < p.M && k + j < p.K);
+            }
+        }
+        if (PRO_B) {
+            constexpr int TPR = BN / 4, KPP = 256 / TPR;
+            const int gcol = n0 + (tid % TPR) * 4;
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = kt * BK + tid / TPR + KPP * i;     // = row of the activation matrix
+                const bool okr = k < p.K;
+                const float mu = (p.has_ln && okr) ? p.pmu[k] : 0.f;
+                const float rs = (p.has_ln && okr) ? p.prs[k] : 1.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rb[i][j] = pro_one<ACT>(rb[i][j], mu, rs, gam_b[j], bet_b[j], p, k, gcol + j,
+                                            okr && gcol + j < p.N);
+            }
+        }
+        store_tile<BM, A_KC>(As, tid, ra);
+        store_tile<BN, B_KC>(Bs, tid, rb);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (kt0 < kt1) {
+        fetch(kt0);
+        commit(kt0, 0);
+    }
+    __syncthreads();
+
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = kt + 1 < kt1;
+        if (more) fetch(kt + 1);                       // global loads in flight under the MFMAs
+        const float* As = smem + stage * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + l31, ks, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + l31, ks, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) commit(kt + 1, stage ^ 1);
+        __syncthreads();
+        stage ^= 1;
+    }
+
+    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const bool split = p.ksplit > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v += bv;
+                    if (p.addend) v += p.addend[(size_t)row * p.ld_addend + col];
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+// split-K combine: deterministic slab sum + epilogue terms
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmParams p) {
+    const size_t total = (size_t)p.M * p.N;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+        float v = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) v += p.slab[(size_t)z * total + idx];
+        if (p.bias) v += p.bias[col];
+        if (p.addend) v += p.addend[(size_t)row * p.ld_addend + col];
+        float* c = p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) v += *c;
+        *c = v;
+    }
+}
+
+struct SplitPlan { int ksplit, kt_per; };
+
+SplitPlan plan_split(int M, int N, int K, int bm, int bn) {
+    const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, bn);
+    const int ktotal = wf3d_cdiv(K, BK);
+    SplitPlan s{1, ktotal};
+    if (tiles >= 256 || ktotal < 8) return s;
+    int want = (int)((512 + tiles - 1) / tiles);
+    int ks = want < ktotal / 4 ? want : ktotal / 4;
+    if (ks > 64) ks = 64;
+    if (ks < 2) return s;
+    s.kt_per = wf3d_cdiv(ktotal, ks);
+    s.ksplit = wf3d_cdiv(ktotal, s.kt_per);      // no empty split
+    return s;
+}
+
+inline bool small_m(int M) { return M <= 64; }
+
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int ACT, bool PRO>
+void launch(const GemmParams& p, hipStream_t st) {
+    dim3 grid(p.nbm * p.nbn, 1, p.ksplit);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKC, BKC, ACT, PRO>), grid, dim3(256), 0, st, p);
+}
+
+template <bool AKC, bool BKC, int ACT, bool PRO>
+void launch_tile(const GemmParams& p, bool small, hipStream_t st) {
+    if (small) launch<1, 4, 1, 1, AKC, BKC, ACT, PRO>(p, st);
+    else       launch<2, 2, 2, 2, AKC, BKC, ACT, PRO>(p, st);
+}
+
+}  // namespace
+
+extern "C" size_t wf3d_gemm_ws_bytes(int M, int N, int K, int layout) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const bool small = layout != WF3D_TN && small_m(M);
+    SplitPlan s = plan_split(M, N, K, small ? 32 : 128, 128);
+    return s.ksplit > 1 ? (size_t)s.ksplit * M * N * sizeof(float) : 0;
+}
+
+extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
+    WF3D_CHECK(d != nullptr, WF3D_ERR_ARG, "wf3d_gemm: null descriptor");
+    WF3D_CHECK(d->M >= 0 && d->N >= 0 && d->K >= 0, WF3D_ERR_ARG, "wf3d_gemm: negative dims");
+    if (d->M == 0 || d->N == 0) return WF3D_OK;
+    WF3D_CHECK(d->A && d->B && d->C, WF3D_ERR_ARG, "wf3d_gemm: null operand");
+    WF3D_CHECK(d->layout >= WF3D_NT && d->layout <= WF3D_TN, WF3D_ERR_ARG, "wf3d_gemm: bad layout %d", d->layout);
+    WF3D_CHECK(d->K > 0, WF3D_ERR_ARG, "wf3d_gemm: K must be > 0");
+    const bool a_kc = d->layout != WF3D_TN, b_kc = d->layout == WF3D_NT;
+    WF3D_CHECK(d->lda >= (a_kc ? d->K : d->M), WF3D_ERR_ARG, "wf3d_gemm: lda %d too small", d->lda);
+    WF3D_CHECK(d->ldb >= (b_kc ? d->K : d->N), WF3D_ERR_ARG, "wf3d_gemm: ldb %d too small", d->ldb);
+    WF3D_CHECK(d->ldc >= d->N, WF3D_ERR_ARG, "wf3d_gemm: ldc %d < N %d", d->ldc, d->N);
+    WF3D_CHECK(!d->addend || d->ld_addend >= d->N, WF3D_ERR_ARG, "wf3d_gemm: ld_addend too small");
+    WF3D_CHECK(!(d->pro_enable && d->layout == WF3D_NN), WF3D_ERR_UNSUPPORTED, "wf3d_gemm: no prologue for NN layout");
+    WF3D_CHECK(!d->pro_enable || (d->pro_act >= 0 && d->pro_act <= 2), WF3D_ERR_ARG, "wf3d_gemm: bad pro_act");
+    WF3D_CHECK(!d->pro_enable || !d->pro_mu || d->pro_rs, WF3D_ERR_ARG, "wf3d_gemm: pro_mu without pro_rs");
+    WF3D_CHECK(!d->pro_enable || !d->pro_gamma || d->pro_beta, WF3D_ERR_ARG, "wf3d_gemm: pro_gamma without pro_beta");
+    WF3D_CHECK(d->drop_p >= 0.f && d->drop_p < 1.f, WF3D_ERR_ARG, "wf3d_gemm: drop_p out of range");
+
+    GemmParams p{};
+    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.addend = d->addend;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.ld_addend = d->ld_addend;
+    p.pmu = d->pro_mu; p.prs = d->pro_rs; p.pgam = d->pro_gamma; p.pbet = d->pro_beta;
+    p.has_ln = d->pro_enable && d->pro_mu != nullptr;
+    p.has_affine = d->pro_enable && d->pro_gamma != nullptr;
+    if (d->pro_enable && d->drop_p > 0.f) {
+        p.drop_seed = d->drop_seed;
+        p.drop_thresh = (uint32_t)((double)d->drop_p * 4294967296.0);
+        p.drop_scale = 1.0f / (1.0f - d->drop_p);
+    }
+    p.accumulate = d->accumulate;
+    p.vecA = ((uintptr_t)d->A % 16 == 0) && (d->lda % 4 == 0);
+    p.vecB = ((uintptr_t)d->B % 16 == 0) && (d->ldb % 4 == 0);
+
+    const bool small = d->layout != WF3D_TN && small_m(d->M);
+    const int bm = small ? 32 : 128, bn = 128;
+    p.nbm = wf3d_cdiv(d->M, bm);
+    p.nbn = wf3d_cdiv(d->N, bn);
+    SplitPlan s = plan_split(d->M, d->N, d->K, bm, bn);
+    const size_t need = s.ksplit > 1 ? (size_t)s.ksplit * d->M * d->N * sizeof(float) : 0;
+    if (need && (d->ws == nullptr || d->ws_bytes < need)) { s.ksplit = 1; s.kt_per = wf3d_cdiv(d->K, BK); }
+    p.ksplit = s.ksplit; p.kt_per_split = s.kt_per;
+    p.slab = s.ksplit > 1 ? (float*)d->ws : nullptr;
+
+    hipStream_t st = (hipStream_t)stream;
+    const int act = d->pro_enable ? d->pro_act : 0;
+    const bool pro = d->pro_enable != 0;
+    if (d->layout == WF3D_NT) {
+        if (!pro)                         launch_tile<true, true, 0, false>(p, small, st);
+        else if (act == WF3D_ACT_RELU)    launch_tile<true, true, WF3D_ACT_RELU, true>(p, small, st);
+        else if (act == WF3D_ACT_GELU)    launch_tile<true, true, WF3D_ACT_GELU, true>(p, small, st);
+        else                              launch_tile<true, true, WF3D_ACT_NONE, true>(p, small, st);
+    } else if (d->layout == WF3D_NN) {
+        launch_tile<true, false, 0, false>(p, small, st);
+    } else {
+        if (!pro)                         launch<2, 2, 2, 2, false, false, 0, false>(p, st);
+        else if (act == WF3D_ACT_RELU)    launch<2, 2, 2, 2, false, false, WF3D_ACT_RELU, true>(p, st);
+        else if (act == WF3D_ACT_GELU)    launch<2, 2, 2, 2, false, false, WF3D_ACT_GELU, true>(p, st);
+        else                              launch<2, 2, 2, 2, false, false, WF3D_ACT_NONE, true>(p, st);
+    }
+    WF3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const size_t total = (size_t)p.M * p.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        WF3D_LAUNCH_CHECK();
+    }
+    return WF3D_OK;
+}

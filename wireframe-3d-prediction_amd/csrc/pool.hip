@@ -1,0 +1,173 @@
+// Fused 4-way pooling over point_features [B, N, C] (HBM-bound, one pass).
+//
+// The reference reads point_features four times (masked mean + masked max in
+// PointNetEncoder.py:103-111, unmasked mean + max in VertexPredictor.py:86-88);
+// here one streaming pass yields all four reductions plus the two arg-max index
+// vectors the backward scatter needs.  Thread = channel (coalesced 256-B rows
+// per wave), the N axis is split over blockIdx.y so that B*nsplit*C/256 >> 256
+// workgroups fill the chip; a tiny second kernel folds the splits in index
+// order (first-max tie rule of torch.max: smallest n wins).
+#include "wf3d_common.h"
+
+namespace {
+
+struct PoolPart {           // per (b, split, c)
+    float msum, usum, mmax, umax;
+    int arg_m, arg_u;
+};
+
+__global__ __launch_bounds__(256) void point_valid_kernel(const float* __restrict__ x, int M, int in_dim,
+                                                           float* __restrict__ valid) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < in_dim; ++k) s += fabsf(x[(size_t)m * in_dim + k]);
+    valid[m] = s > 1e-9f ? 1.0f : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void pool4_partial_kernel(const float* __restrict__ pf, const float* __restrict__ valid,
+                                                             int N, int C, int nsplit, int npb,
+                                                             PoolPart* __restrict__ part, float* __restrict__ cnt_part) {
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = sp * npb, n1 = min(N, n0 + npb);
+    float msum = 0.f, usum = 0.f, mmax = -INFINITY, umax = -INFINITY, cnt = 0.f;
+    int am = -1, au = -1;
+    if (c < C) {
+        const float* p = pf + ((size_t)b * N + n0) * C + c;
+        const float* vp = valid + (size_t)b * N;
+        for (int n = n0; n < n1; ++n, p += C) {
+            const float v = *p;
+            const float ok = vp[n];
+            usum += v;
+            if (v > umax || au < 0) { umax = v; au = n; }
+            if (ok != 0.f) {
+                msum += v; cnt += 1.f;
+                if (v > mmax || am < 0) { mmax = v; am = n; }
+            }
+        }
+        PoolPart o{msum, usum, mmax, umax, am, au};
+        part[((size_t)b * nsplit + sp) * C + c] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt_part[b * nsplit + sp] = cnt;
+}
+
+__global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __restrict__ part,
+                                                           const float* __restrict__ cnt_part, int N, int C,
+                                                           int nsplit, float* __restrict__ mmax_o,
+                                                           float* __restrict__ mavg_o, float* __restrict__ umean_o,
+                                                           float* __restrict__ umax_o, int32_t* __restrict__ arg_m_o,
+                                                           int32_t* __restrict__ arg_u_o, float* __restrict__ cnt_o) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float cnt = 0.f;
+    for (int s = 0; s < nsplit; ++s) cnt += cnt_part[b * nsplit + s];
+    const float cl = fmaxf(cnt, 1.0f);                      // clamp(min=1), PointNetEncoder.py:86
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt_o[b] = cl;
+    if (c >= C) return;
+    float msum = 0.f, usum = 0.f, mmax = -INFINITY, umax = -INFINITY;
+    int am = -1, au = -1;
+    for (int s = 0; s < nsplit; ++s) {
+        const PoolPart q = part[((size_t)b * nsplit + s) * C + c];
+        msum += q.msum; usum += q.usum;
+        if (q.arg_u >= 0 && (q.umax > umax || au < 0)) { umax = q.umax; au = q.arg_u; }
+        if (q.arg_m >= 0 && (q.mmax > mmax || am < 0)) { mmax = q.mmax; am = q.arg_m; }
+    }
+    const size_t o = (size_t)b * C + c;
+    // where(isfinite(max), max, 0): a cloud with no valid point pools to 0 and passes no gradient
+    const bool fin = am >= 0 && isfinite(mmax);
+    mmax_o[o] = fin ? mmax : 0.f;
+    arg_m_o[o] = fin ? am : -1;
+    mavg_o[o] = msum / cl;
+    umean_o[o] = usum / (float)N;
+    umax_o[o] = umax;
+    arg_u_o[o] = au;
+}
+
+__global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict__ valid, const float* __restrict__ cnt,
+                                                         const int32_t* __restrict__ arg_m, const int32_t* __restrict__ arg_u,
+                                                         const float* __restrict__ dmmax, const float* __restrict__ dmavg,
+                                                         const float* __restrict__ dumean, const float* __restrict__ dumax,
+                                                         const float* __restrict__ dpf_direct, int N, int C,
+                                                         int npb, float* __restrict__ dpf) {
+    const int b = blockIdx.z;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int n0 = blockIdx.y * npb, n1 = min(N, n0 + npb);
+    const size_t o = (size_t)b * C + c;
+    const float g_avg = dmavg ? dmavg[o] / cnt[b] : 0.f;
+    const float g_mean = dumean ? dumean[o] / (float)N : 0.f;
+    const float g_mm = dmmax ? dmmax[o] : 0.f;
+    const float g_um = dumax ? dumax[o] : 0.f;
+    const int am = arg_m[o], au = arg_u[o];
+    for (int n = n0; n < n1; ++n) {
+        const size_t idx = ((size_t)b * N + n) * C + c;
+        float g = g_mean + valid[(size_t)b * N + n] * g_avg;
+        if (n == am) g += g_mm;
+        if (n == au) g += g_um;
+        if (dpf_direct) g += dpf_direct[idx];
+        dpf[idx] = g;
+    }
+}
+
+int pool_nsplit(int B, int N, int C) {
+    const int cb = wf3d_cdiv(C, 256);
+    int ns = 2048 / (B * cb > 0 ? B * cb : 1);
+    const int cap = wf3d_cdiv(N, 32);
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+}  // namespace
+
+extern "C" int wf3d_point_valid(const float* x, int M, int in_dim, float* valid, void* stream) {
+    WF3D_CHECK(M >= 0 && in_dim > 0, WF3D_ERR_ARG, "wf3d_point_valid: bad dims");
+    if (M == 0) return WF3D_OK;
+    WF3D_CHECK(x && valid, WF3D_ERR_ARG, "wf3d_point_valid: null pointer");
+    hipLaunchKernelGGL(point_valid_kernel, dim3(wf3d_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, x, M, in_dim, valid);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" size_t wf3d_pool4_ws_bytes(int B, int N, int C) {
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    const int ns = pool_nsplit(B, N, C);
+    size_t bytes = (size_t)B * ns * C * sizeof(PoolPart);
+    bytes = (bytes + 255) & ~(size_t)255;
+    return bytes + (size_t)B * ns * sizeof(float);
+}
+
+extern "C" int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N, int C, float* mmax, float* mavg,
+                              float* umean, float* umax, int32_t* arg_m, int32_t* arg_u, float* cnt, void* ws,
+                              size_t ws_bytes, void* stream) {
+    WF3D_CHECK(B > 0 && N > 0 && C > 0, WF3D_ERR_ARG, "wf3d_pool4_fwd: bad dims B=%d N=%d C=%d", B, N, C);
+    WF3D_CHECK(B <= 65535, WF3D_ERR_UNSUPPORTED, "wf3d_pool4_fwd: B > 65535");
+    WF3D_CHECK(pf && valid && mmax && mavg && umean && umax && arg_m && arg_u && cnt, WF3D_ERR_ARG, "wf3d_pool4_fwd: null pointer");
+    WF3D_CHECK(ws && ws_bytes >= wf3d_pool4_ws_bytes(B, N, C), WF3D_ERR_WS, "wf3d_pool4_fwd: workspace too small");
+    const int ns = pool_nsplit(B, N, C);
+    const int npb = wf3d_cdiv(N, ns);
+    PoolPart* part = (PoolPart*)ws;
+    size_t off = ((size_t)B * ns * C * sizeof(PoolPart) + 255) & ~(size_t)255;
+    float* cnt_part = (float*)((char*)ws + off);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pool4_partial_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, st, pf, valid, N, C, ns, npb, part, cnt_part);
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pool4_final_kernel, dim3(wf3d_cdiv(C, 256), B), dim3(256), 0, st, part, cnt_part, N, C, ns, mmax,
+                       mavg, umean, umax, arg_m, arg_u, cnt);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
+                              const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                              const float* dpf_direct, int B, int N, int C, float* dpf, void* stream) {
+    WF3D_CHECK(B > 0 && N > 0 && C > 0 && B <= 65535, WF3D_ERR_ARG, "wf3d_pool4_bwd: bad dims");
+    WF3D_CHECK(valid && cnt && arg_m && arg_u && dpf, WF3D_ERR_ARG, "wf3d_pool4_bwd: null pointer");
+    const int ns = pool_nsplit(B, N, C);
+    const int npb = wf3d_cdiv(N, ns);
+    hipLaunchKernelGGL(pool4_bwd_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, (hipStream_t)stream, valid, cnt,
+                       arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}

@@ -1,0 +1,306 @@
+// Row-wise LayerNorm pieces and column reductions (HBM-bound kernels).
+//
+// Layout: activations are row-major [R, D]; one wave64 owns one row at a time
+// and reads it as 16-B-per-lane coalesced float4 (lane l, slot i -> columns
+// 4l + 256i ...), so every wave-instruction moves 1 KiB contiguous.
+#include "wf3d_common.h"
+
+namespace {
+
+__device__ __forceinline__ bool vec_ok(const void* p, int ld, int D) {
+    return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0) && (D % 4 == 0);
+}
+
+// ---- row_stats: mu, rstd per row (two-pass, second pass served by L1/L2) -----
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ z, int R, int D, int ld,
+                                                         float eps, float* __restrict__ mu, float* __restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* p = z + (size_t)row * ld;
+    const bool vec = vec_ok(z, ld, D);
+    float s = 0.f;
+    if (vec) {
+        for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) s += p[c];
+    }
+    const float mean = wf3d_wave_sum(s) / (float)D;
+    float q = 0.f;
+    if (vec) {
+        for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; q += d * d; }
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) { const float d = p[c] - mean; q += d * d; }
+    }
+    const float var = wf3d_wave_sum(q) / (float)D;
+    if (lane == 0) {
+        mu[row] = mean;
+        rs[row] = 1.0f / sqrtf(var + eps);
+    }
+}
+
+// ---- ln_act_apply: out = drop(act(LN(z))) + addend ---------------------------
+__global__ __launch_bounds__(256) void ln_act_apply_kernel(const float* __restrict__ z, int R, int D,
+                                                            const float* __restrict__ mu, const float* __restrict__ rs,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int act, const float* __restrict__ addend, uint32_t seed,
+                                                            uint32_t thresh, float scale, float* __restrict__ out) {
+    const size_t total = (size_t)R * D;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / D), c = (int)(idx % D);
+        float y = z[idx];
+        if (mu) y = (y - mu[r]) * rs[r];
+        if (gamma) y = y * gamma[c] + beta[c];
+        y = wf3d_act_rt(act, y);
+        if (thresh) y = wf3d_keep(seed, (uint32_t)r, (uint32_t)c, thresh) ? y * scale : 0.f;
+        if (addend) y += addend[idx];
+        out[idx] = y;
+    }
+}
+
+// ---- ln_act_bwd ---------------------------------------------------------------
+// h = drop(act(y)), y = xhat*gamma + beta, xhat = (z - mu) * rs.
+//   g      = dh * dropmask * act'(y)
+//   dgamma = sum_r g*xhat ; dbeta = sum_r g
+//   dz     = rs * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))
+//   dbias  = sum_r dz                                  
+// Each wave keeps its row (z, dh) in registers (NS float4 slots per lane), so
+// z and dh are read from HBM exactly once; column partials live in registers
+// across the block's rows and are combined through LDS, then per-block
+// partials [nblk][3][D] are summed by colsum_finalize (deterministic, no atomics).
+template <int NS>
+__global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z,
+                                                          int R, int D, const float* __restrict__ mu,
+                                                          const float* __restrict__ rs, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int act, uint32_t seed,
+                                                          uint32_t thresh, float scale, float* __restrict__ dz,
+                                                          float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [3][D] block combine
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool has_ln = mu != nullptr;
+    f32x4 gam[NS], bet[NS];
+    f32x4 a_dg[NS], a_db[NS], a_dbias[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane * 4 + 256 * i;
+        gam[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        bet[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (gamma && c < D) {
+            gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+            bet[i] = *reinterpret_cast<const f32x4*>(beta + c);
+        }
+        a_dg[i] = a_db[i] = a_dbias[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float invD = 1.0f / (float)D;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const float m = has_ln ? mu[row] : 0.f, r = has_ln ? rs[row] : 1.f;
+        f32x4 xh[NS], gg[NS];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 4 + 256 * i;
+            xh[i] = gg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < D) {
+                const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = (zv[j] - m) * r;
+                    const float y = x * gam[i][j] + bet[i][j];
+                    float d = dv[j];
+                    if (thresh) d = wf3d_keep(seed, (uint32_t)row, (uint32_t)(c + j), thresh) ? d * scale : 0.f;
+                    const float g = d * wf3d_act_grad_rt(act, y);
+                    xh[i][j] = x; gg[i][j] = g;
+                    const float gy = g * gam[i][j];
+                    s1 += gy; s2 += gy * x;
+                }
+            }
+        }
+        float c1 = 0.f, c2 = 0.f;
+        if (has_ln) { c1 = wf3d_wave_sum(s1) * invD; c2 = wf3d_wave_sum(s2) * invD; }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g = gg[i][j], x = xh[i][j];
+                    o[j] = has_ln ? r * (g * gam[i][j] - c1 - x * c2) : g;
+                    a_dg[i][j] += g * x; a_db[i][j] += g; a_dbias[i][j] += o[j];
+                }
+                *reinterpret_cast<f32x4*>(dz + (size_t)row * D + c) = o;
+            }
+        }
+    }
+    // block combine of the 4 waves' column partials, then one partial row per block
+    for (int k = 0; k < 3; ++k) {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int c = lane * 4 + 256 * i;
+                    if (c < D) {
+                        f32x4 v = k == 0 ? a_dg[i] : (k == 1 ? a_db[i] : a_dbias[i]);
+                        f32x4* dst = reinterpret_cast<f32x4*>(red + k * D + c);
+                        if (w) v += *dst;
+                        *dst = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = threadIdx.x; idx < 3 * D; idx += 256) part[(size_t)blockIdx.x * 3 * D + idx] = red[idx];
+}
+
+// out[c] = sum_b part[b*stride + c]
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, size_t stride,
+                                                               int D, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += part[(size_t)b * stride + c];
+        s1 += part[(size_t)(b + 1) * stride + c];
+        s2 += part[(size_t)(b + 2) * stride + c];
+        s3 += part[(size_t)(b + 3) * stride + c];
+    }
+    for (; b < nblk; ++b) s0 += part[(size_t)b * stride + c];
+    out[c] = (s0 + s1) + (s2 + s3);
+}
+
+// partial column sums: block (bx, by) sums rows [by*rpb, ...) of columns bx*256..
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int R, int D, int ld,
+                                                              const float* __restrict__ w, int rpb,
+                                                              float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const int r0 = blockIdx.y * rpb, r1 = min(R, r0 + rpb);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + c] * (w ? w[r] : 1.0f);
+    part[(size_t)blockIdx.y * D + c] = s;
+}
+
+int bwd_nblk(int R) {
+    int n = wf3d_cdiv(R, 4);
+    return n > 1024 ? 1024 : (n < 1 ? 1 : n);
+}
+int colsum_nrb(int R) {
+    int n = wf3d_cdiv(R, 64);
+    return n > 512 ? 512 : (n < 1 ? 1 : n);
+}
+
+}  // namespace
+
+extern "C" int wf3d_row_stats(const float* z, int R, int D, int ld, float eps, float* mu, float* rs, void* stream) {
+    WF3D_CHECK(R >= 0 && D > 0 && ld >= D, WF3D_ERR_ARG, "wf3d_row_stats: bad dims R=%d D=%d ld=%d", R, D, ld);
+    if (R == 0) return WF3D_OK;
+    WF3D_CHECK(z && mu && rs, WF3D_ERR_ARG, "wf3d_row_stats: null pointer");
+    hipLaunchKernelGGL(row_stats_kernel, dim3(wf3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, z, R, D, ld, eps, mu, rs);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_ln_act_apply(const float* z, int R, int D, const float* mu, const float* rs,
+                                 const float* gamma, const float* beta, int act, const float* addend,
+                                 float drop_p, uint32_t drop_seed, float* out, void* stream) {
+    WF3D_CHECK(R >= 0 && D > 0, WF3D_ERR_ARG, "wf3d_ln_act_apply: bad dims");
+    if (R == 0) return WF3D_OK;
+    WF3D_CHECK(z && out, WF3D_ERR_ARG, "wf3d_ln_act_apply: null pointer");
+    WF3D_CHECK(!mu || rs, WF3D_ERR_ARG, "wf3d_ln_act_apply: mu without rs");
+    WF3D_CHECK(!gamma || beta, WF3D_ERR_ARG, "wf3d_ln_act_apply: gamma without beta");
+    WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_ln_act_apply: bad act/drop");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float scale = 1.0f / (1.0f - drop_p);
+    const size_t total = (size_t)R * D;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ln_act_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, R, D, mu, rs, gamma,
+                       beta, act, addend, drop_seed, thresh, scale, out);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" size_t wf3d_ln_act_bwd_ws_bytes(int R, int D) {
+    if (R <= 0 || D <= 0) return 0;
+    return (size_t)bwd_nblk(R) * 3 * D * sizeof(float);
+}
+
+extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, const float* mu, const float* rs,
+                               const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
+                               float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                               void* stream) {
+    WF3D_CHECK(R >= 0 && D > 0, WF3D_ERR_ARG, "wf3d_ln_act_bwd: bad dims");
+    WF3D_CHECK(D % 4 == 0 && D <= 4096, WF3D_ERR_UNSUPPORTED, "wf3d_ln_act_bwd: D=%d must be a multiple of 4, <= 4096", D);
+    WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_ln_act_bwd: bad act/drop");
+    WF3D_CHECK(!mu || rs, WF3D_ERR_ARG, "wf3d_ln_act_bwd: mu without rs");
+    WF3D_CHECK(!gamma || beta, WF3D_ERR_ARG, "wf3d_ln_act_bwd: gamma without beta");
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        if (dgamma) hipMemsetAsync(dgamma, 0, D * sizeof(float), st);
+        if (dbeta) hipMemsetAsync(dbeta, 0, D * sizeof(float), st);
+        if (dbias) hipMemsetAsync(dbias, 0, D * sizeof(float), st);
+        return WF3D_OK;
+    }
+    WF3D_CHECK(dh && z && dz, WF3D_ERR_ARG, "wf3d_ln_act_bwd: null pointer");
+    WF3D_CHECK(((uintptr_t)dh % 16 == 0) && ((uintptr_t)z % 16 == 0) && ((uintptr_t)dz % 16 == 0) &&
+               (!gamma || ((uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0)),
+               WF3D_ERR_ARG, "wf3d_ln_act_bwd: pointers must be 16-byte aligned");
+    const int nblk = bwd_nblk(R);
+    WF3D_CHECK(ws && ws_bytes >= (size_t)nblk * 3 * D * sizeof(float), WF3D_ERR_WS, "wf3d_ln_act_bwd: workspace too small");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float scale = 1.0f / (1.0f - drop_p);
+    float* part = (float*)ws;
+    const size_t lds = (size_t)3 * D * sizeof(float);
+    const int ns = wf3d_cdiv(D, 256);
+#define WF3D_BWD(NS_)                                                                                              \
+    hipLaunchKernelGGL((ln_act_bwd_kernel<NS_>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
+                       act, drop_seed, thresh, scale, dz, part)
+    if (ns <= 1) WF3D_BWD(1);
+    else if (ns <= 2) WF3D_BWD(2);
+    else if (ns <= 4) WF3D_BWD(4);
+    else if (ns <= 8) WF3D_BWD(8);
+    else WF3D_BWD(16);
+#undef WF3D_BWD
+    WF3D_LAUNCH_CHECK();
+    float* outs[3] = {dgamma, dbeta, dbias};
+    for (int k = 0; k < 3; ++k) {
+        if (!outs[k]) continue;
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 256)), dim3(256), 0, st, part + (size_t)k * D, nblk,
+                           (size_t)3 * D, D, outs[k]);
+        WF3D_LAUNCH_CHECK();
+    }
+    return WF3D_OK;
+}
+
+extern "C" size_t wf3d_colsum_ws_bytes(int R, int D) {
+    if (R <= 0 || D <= 0) return 0;
+    return (size_t)colsum_nrb(R) * D * sizeof(float);
+}
+
+extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, float* out, void* ws,
+                           size_t ws_bytes, void* stream) {
+    WF3D_CHECK(R >= 0 && D > 0 && ld >= D && out, WF3D_ERR_ARG, "wf3d_colsum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) { hipMemsetAsync(out, 0, D * sizeof(float), st); return WF3D_OK; }
+    WF3D_CHECK(x, WF3D_ERR_ARG, "wf3d_colsum: null x");
+    const int nrb = colsum_nrb(R);
+    WF3D_CHECK(ws && ws_bytes >= (size_t)nrb * D * sizeof(float), WF3D_ERR_WS, "wf3d_colsum: workspace too small");
+    const int rpb = wf3d_cdiv(R, nrb);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(wf3d_cdiv(D, 256), nrb), dim3(256), 0, st, x, R, D, ld, w, rpb, part);
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 256)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
+                       (size_t)D, D, out);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}

@@ -1,0 +1,82 @@
+// Shared device/host helpers for the wf3d HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/wf3d.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WF3D_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------
+void wf3d_set_error(const char* fmt, ...);
+#define WF3D_CHECK(cond, code, ...)                \
+    do {                                           \
+        if (!(cond)) {                             \
+            wf3d_set_error(__VA_ARGS__);           \
+            return (code);                         \
+        }                                          \
+    } while (0)
+#define WF3D_LAUNCH_CHECK()                                                   \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess) {                                               \
+            wf3d_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,     \
+                           hipGetErrorString(e_));                            \
+            return WF3D_ERR_LAUNCH;                                           \
+        }                                                                     \
+    } while (0)
+
+static inline int wf3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers --------------------------------------------------------
+#ifdef __HIPCC__
+// activations used on the path: ReLU (encoder / vertex head), erf-GELU (edge head)
+template <int ACT>
+__device__ __forceinline__ float wf3d_act(float y) {
+    if (ACT == WF3D_ACT_RELU) return fmaxf(y, 0.0f);
+    if (ACT == WF3D_ACT_GELU) return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    return y;
+}
+// d act(y) / dy
+template <int ACT>
+__device__ __forceinline__ float wf3d_act_grad(float y) {
+    if (ACT == WF3D_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    if (ACT == WF3D_ACT_GELU) {
+        const float cdf = 0.5f * (1.0f + erff(y * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * y * y);
+        return cdf + y * pdf;
+    }
+    return 1.0f;
+}
+__device__ __forceinline__ float wf3d_act_rt(int act, float y) {
+    return act == WF3D_ACT_RELU ? wf3d_act<WF3D_ACT_RELU>(y)
+         : act == WF3D_ACT_GELU ? wf3d_act<WF3D_ACT_GELU>(y) : y;
+}
+__device__ __forceinline__ float wf3d_act_grad_rt(int act, float y) {
+    return act == WF3D_ACT_RELU ? wf3d_act_grad<WF3D_ACT_RELU>(y)
+         : act == WF3D_ACT_GELU ? wf3d_act_grad<WF3D_ACT_GELU>(y) : 1.0f;
+}
+
+// Counter-based dropout keep-mask: the same (seed,row,col) gives the same bit
+// in the forward prologue and in the backward kernels, so masks are never stored.
+__device__ __forceinline__ bool wf3d_keep(uint32_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
+    uint32_t h = seed ^ (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u + 0x27D4EB2Fu);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h >= thresh;
+}
+
+__device__ __forceinline__ float wf3d_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wf3d_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif
