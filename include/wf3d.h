@@ -138,6 +138,58 @@ int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, c
                    const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
                    const float* dpf_direct, int B, int N, int C, float* dpf, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Vertex head tail (VertexPredictor.py:118-127): existence = sigmoid(o[:,:,3]),
+ * actual_vertex_counts = sum(existence > 0.5) (int64), o = final_layer output
+ * [B, V, vertex_dim >= 4]; backward: d_o = d_o_in (grad that reached o through the
+ * vertices view, may be NULL) with dexist*p*(1-p) added into channel 3.
+ * ------------------------------------------------------------------------ */
+int wf3d_vertex_finalize_fwd(const float* o, int B, int V, int vertex_dim, float* exist, int64_t* counts,
+                             void* stream);
+int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const float* d_o_in, int B, int V,
+                             int vertex_dim, float* d_o, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Edge head (EdgePredictor.py:91-140, PointCloudToWireframe.py:77-112), batched
+ * over samples with COMPACT ragged rows instead of the reference's serial
+ * batch-1 loop: sample s owns vertex rows voff[s]..voff[s+1]-1 (its first
+ * counts[s] predicted vertices) and edge rows eoff[s]..eoff[s+1]-1 (all pairs
+ * i<j in lexicographic order); vsample/esample map a row back to its sample.
+ * ------------------------------------------------------------------------ */
+/* cv[r,0:3] = verts[s, r-voff[s], 0:3]; strides in floats (vertices is a view of [B,V,4]) */
+int wf3d_edge_gather_verts(const float* verts, long sample_stride, long vertex_stride, const int32_t* voff,
+                           const int32_t* vsample, int Rv, float* cv, void* stream);
+/* dverts[B,V,3] = scatter of dcv rows, zero for v >= counts[s] */
+int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V, float* dverts, void* stream);
+
+/* 8-head self-attention of nn.MultiheadAttention (EdgePredictor.py:41-46,109):
+ * qkv[Rv, 3E] packed in_proj output; one workgroup per (head, sample); writes
+ * ctx[Rv, E] (heads concatenated, before out_proj) and lse[Rv, heads]. */
+int wf3d_attn_fwd(const float* qkv, const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
+                  uint32_t drop_seed, float* ctx, float* lse, void* stream);
+int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* lse, const int32_t* voff, int S, int vmax,
+                  int E, int heads, float drop_p, uint32_t drop_seed, float* dqkv, void* stream);
+
+/* Split first layer of edge_mlp (EdgePredictor.py:122-137):
+ * pre[e,:] = Pa[i,:] + Pb[j,:] + |c_i - c_j| * wdelta  for edge e = (i, j), plus
+ * the row's LayerNorm statistics and delta[e] = |c_i - c_j|.  wdelta is column
+ * 2H+6 of edge_mlp.0.weight, read with stride wdelta_stride (= 2H+7). */
+int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
+                       const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
+                       float* pre, float* mu, float* rs, float* delta, void* stream);
+/* dPa[v] / dPb[v] = segmented sums of dpre over the edges where v is i / j, and
+ * dcv[v] = sum over incident edges of (dpre[e]·wdelta)(c_v - c_other)/delta[e]. */
+int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,
+                       int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample, int Rv,
+                       int H, float* dPa, float* dPb, float* dcv, void* stream);
+
+/* probs[s, e - eoff[s]] = sigmoid(logit[e]) into the zero-initialised padded
+ * [B, max_e] output (PointCloudToWireframe.py:103-112), and its backward. */
+int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, const int32_t* esample, int Re, int max_e,
+                       float* probs, void* stream);
+int wf3d_edge_prob_bwd(const float* probs, const float* dprobs, const int32_t* eoff, const int32_t* esample, int Re,
+                       int max_e, float* dlogit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,246 @@
+"""Stage-level and whole-model parity of the HIP path (through the C ABI and the
+drop-in classes) against (a) the golden fixtures produced from the reference and
+(b) the CPU oracle on the same inputs.  Tolerance (BASELINE.json north_star):
+1e-4 relative fp32 on outputs, bit-exact edge index lists; gradients are held
+to 1e-3 of each tensor's scale (they pass through arg-max routing and ~10 chained
+GEMMs in a different summation order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import helpers as H  # noqa: E402
+from helpers import detgen, oracle  # noqa: E402
+
+TOL_OUT = 1e-4
+TOL_GRAD = 1e-3
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def load_arrays(module, arrs, prefix=""):
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            v.copy_(torch.from_numpy(arrs[prefix + k]))
+
+
+def test_small_encoder_vs_golden():
+    from models.PointNetEncoder import PointNetEncoder
+    gold = H.load_golden("small_enc")
+    shapes = H.sub_shapes("encoder.", input_dim=8, hidden_dims=(32, 64), output_dim=16)
+    enc = PointNetEncoder(8, [32, 64], 16).to(dev())
+    load_arrays(enc, detgen.fill_state_dict(shapes, 3))
+    x = torch.from_numpy(H.make_cloud("small_enc.x", 3, 37, 3, pad_frac=0.2, dead_cloud=2)).to(dev())
+    g, pf = enc(x)
+    assert H.rel_err(g.detach().cpu().numpy(), gold["out.global"]) < TOL_OUT
+    assert H.rel_err(pf.detach().cpu().numpy(), gold["out.point_features"]) < TOL_OUT
+    cg = torch.from_numpy(detgen.uniform("small_enc.cot.g", tuple(g.shape), -1, 1, 3)).to(dev())
+    cp = torch.from_numpy(detgen.uniform("small_enc.cot.pf", tuple(pf.shape), -1, 1, 3)).to(dev())
+    ((g * cg).sum() + (pf * cp).sum()).backward()
+    for n, p in enc.named_parameters():
+        assert H.rel_err(p.grad.cpu().numpy(), gold["grad." + n]) < TOL_GRAD, n
+
+
+@pytest.mark.parametrize("V", [7, 2])
+def test_small_edge_vs_golden(V):
+    from models.EdgePredictor import EdgePredictor
+    gold = H.load_golden("small_edge")
+    shapes = H.sub_shapes("edge_predictor.", edge_hidden=64)
+    ep = EdgePredictor(3, 64, 2).to(dev())
+    load_arrays(ep, detgen.fill_state_dict(shapes, 4))
+    for sub in ep.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+    ep.attention.dropout = 0.0
+    ep.train()
+    v = torch.from_numpy(detgen.normalish(f"small_edge.v{V}", (2, V, 3), 4)).to(dev()).requires_grad_()
+    probs, idx = ep(v)
+    assert np.array_equal(np.array(idx, dtype=np.int64), gold[f"V{V}.idx"])
+    assert np.array_equal(ep._get_edge_indices(V).cpu().numpy(), gold[f"V{V}.idx"])
+    assert H.rel_err(probs.detach().cpu().numpy(), gold[f"V{V}.probs"]) < TOL_OUT
+    c = torch.from_numpy(detgen.uniform(f"small_edge.cot{V}", tuple(probs.shape), -1, 1, 4)).to(dev())
+    (probs * c).sum().backward()
+    assert H.rel_err(v.grad.cpu().numpy(), gold[f"V{V}.dverts"]) < TOL_GRAD
+    for n, p in ep.named_parameters():
+        key = f"V{V}.grad.{n}"
+        if key in gold:
+            assert H.rel_err(p.grad.cpu().numpy(), gold[key]) < TOL_GRAD, n
+        else:
+            assert p.grad is None, n            # spatial_proj is never used
+
+
+@pytest.mark.parametrize("V", [0, 1])
+def test_edge_degenerate_counts_raise_like_reference(V):
+    from models.EdgePredictor import EdgePredictor
+    ep = EdgePredictor(3, 64, 2).to(dev())
+    with pytest.raises(IndexError):
+        ep(torch.zeros(1, V, 3, device=dev()))
+
+
+def test_small_vertex_vs_golden():
+    from models.VertexPredictor import VertexPredictor
+    gold = H.load_golden("small_vert")
+    shapes = H.sub_shapes("vertex_predictor.", output_dim=16, max_vertices=5)
+    vp = VertexPredictor(16, 5, 4).to(dev())
+    vp.ensure_point_pool_proj(32, dev())
+    load_arrays(vp, detgen.fill_state_dict(shapes, 5))
+    g = torch.from_numpy(detgen.normalish("small_vert.g", (3, 16), 5)).to(dev()).requires_grad_()
+    pf = torch.from_numpy(detgen.normalish("small_vert.pf", (3, 11, 16), 5)).to(dev()).requires_grad_()
+    out = vp(g, pf)
+    assert out["vertices"].shape == (3, 5, 3) and not out["vertices"].is_contiguous()
+    assert H.rel_err(out["vertices"].detach().cpu().numpy(), gold["out.vertices"]) < TOL_OUT
+    assert H.rel_err(out["existence_probabilities"].detach().cpu().numpy(), gold["out.exist"]) < TOL_OUT
+    assert np.array_equal(out["actual_vertex_counts"].cpu().numpy(), gold["out.counts"])
+    assert out["actual_vertex_counts"].dtype == torch.int64
+    cv = torch.from_numpy(detgen.uniform("small_vert.cot.v", (3, 5, 3), -1, 1, 5)).to(dev())
+    ce = torch.from_numpy(detgen.uniform("small_vert.cot.e", (3, 5), -1, 1, 5)).to(dev())
+    ((out["vertices"] * cv).sum() + (out["existence_probabilities"] * ce).sum()).backward()
+    assert H.rel_err(g.grad.cpu().numpy(), gold["grad.g"]) < TOL_GRAD
+    assert H.rel_err(pf.grad.cpu().numpy(), gold["grad.pf"]) < TOL_GRAD
+    bad = H.check_grad_summaries(gold, [(n, p.grad) for n, p in vp.named_parameters()], TOL_GRAD)
+    assert not bad, bad
+    out2 = vp(g.detach(), None)
+    assert H.rel_err(out2["vertices"].detach().cpu().numpy(), gold["out.nopf.vertices"]) < TOL_OUT
+
+
+def build_full(tag):
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    gold = H.load_golden(tag)
+    x, arrs, counts, V, seed, train = H.full_case_inputs(tag, gold)
+    model = PointCloudToWireframe(8, V).to(dev())
+    assert not hasattr(model.vertex_predictor, "point_pool_proj")          # lazy
+    assert len(list(model.parameters())) == 78
+    model.vertex_predictor.ensure_point_pool_proj(1024, dev())
+    assert len(list(model.parameters())) == 80
+    load_arrays(model, arrs)
+    model.set_dropout(0.0)
+    model.train(train)
+    return gold, model, x, arrs, counts, V, seed, train
+
+
+@pytest.mark.parametrize("tag", ["cfg1", "ragged", "evalmode"])
+def test_full_model_vs_golden_and_oracle(tag):
+    gold, model, x, arrs, counts, V, seed, train = build_full(tag)
+    xd = torch.from_numpy(x).to(dev())
+    cd = counts.to(dev()) if counts is not None else None
+    with torch.set_grad_enabled(train):
+        out = model(xd, cd)
+    # structure of the reference's return dict (PointCloudToWireframe.py:114-121)
+    assert list(out.keys()) == ["vertices", "existence_probabilities", "edge_probs", "edge_indices",
+                                "global_features", "actual_vertex_counts"]
+    assert out["edge_probs"].dtype == torch.float32
+    assert np.array_equal(out["actual_vertex_counts"].cpu().numpy(), gold["out.actual_vertex_counts"])
+    lens = [len(e) for e in out["edge_indices"]]
+    assert lens == gold["out.edge_index_lens"].tolist()
+    flat = np.array([ij for e in out["edge_indices"] for ij in e], dtype=np.int64).reshape(-1, 2)
+    assert np.array_equal(flat, gold["out.edge_indices_flat"])                   # bit-exact
+    for k in ("vertices", "existence_probabilities", "edge_probs", "global_features"):
+        assert H.rel_err(out[k].detach().cpu().numpy(), gold["out." + k]) < TOL_OUT, k
+    # padding must be exactly zero
+    ep = out["edge_probs"].detach().cpu().numpy()
+    for s, n in enumerate(lens):
+        assert np.all(ep[s, n:] == 0.0)
+    if train:
+        cot = H.full_case_cotangents(tag, out, seed)
+        loss = sum((out[k] * cot[k].to(dev())).sum() for k in cot)
+        loss.backward()
+        assert abs(loss.item() - float(gold["out.loss"])) < 1e-4 * max(1.0, abs(float(gold["out.loss"])))
+        named = [(n, p.grad) for n, p in model.named_parameters()]
+        bad = H.check_grad_summaries(gold, named, TOL_GRAD)
+        assert not bad, bad
+        for n, g in named:                           # spatial_proj gets no gradient at all
+            if "spatial_proj" in n:
+                assert g is None
+
+
+def test_dropout_train_mode_runs_and_is_seeded():
+    """train() with the reference's p=0.1: outputs differ from p=0, are finite,
+    reproducible under torch.manual_seed, and backward is consistent with forward
+    (finite differences on one weight)."""
+    gold, model, x, arrs, counts, V, seed, train = build_full("ragged")
+    model.set_dropout(0.1)
+    model.train()
+    xd, cd = torch.from_numpy(x).to(dev()), counts.to(dev())
+    torch.manual_seed(7)
+    a = model(xd, cd)["edge_probs"].detach().clone()
+    torch.manual_seed(7)
+    b = model(xd, cd)["edge_probs"].detach().clone()
+    c = model(xd, cd)["edge_probs"].detach().clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.isfinite(a).all()
+    model.set_dropout(0.0)
+    d = model(xd, cd)["edge_probs"].detach()
+    assert (a - d).abs().max() > 1e-3
+    model.eval()
+    with torch.no_grad():
+        e1 = model(xd)["edge_probs"]
+        e2 = model(xd)["edge_probs"]
+    assert torch.equal(e1, e2)
+
+
+def test_edge_head_dropout_gradcheck():
+    """Directional finite-difference check of EdgeFn backward WITH dropout masks on."""
+    from models.EdgePredictor import EdgePredictor
+    torch.manual_seed(3)
+    ep = EdgePredictor(3, 64, 2).to(dev())
+    ep.train()
+    v = torch.randn(3, 6, 3, device=dev()).requires_grad_()
+    counts = [6, 3, 5]
+    cot = torch.randn(3, 15, device=dev())
+
+    def run(vv):
+        torch.manual_seed(11)           # same dropout seed every call
+        return (ep.forward_ragged(vv, counts) * cot).sum()
+
+    loss = run(v)
+    loss.backward()
+    dirn = torch.randn_like(v)
+    eps = 1e-2
+    with torch.no_grad():
+        lp = run(v + eps * dirn).double()
+        lm = run(v - eps * dirn).double()
+    fd = (lp - lm) / (2 * eps)
+    an = (v.grad.double() * dirn.double()).sum()
+    assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd.item(), an.item())
+    w = ep.edge_mlp[4].weight
+    dirw = torch.randn_like(w)
+    an = (w.grad.double() * dirw.double()).sum()
+    with torch.no_grad():
+        w.add_(eps * dirw); lp = run(v).double()
+        w.sub_(2 * eps * dirw); lm = run(v).double()
+        w.add_(eps * dirw)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd.item(), an.item())
+
+
+def test_attention_vs_torch_mha():
+    """wf3d_attn_fwd/bwd against torch's own MultiheadAttention math on ragged samples."""
+    from wf3d import ops
+    torch.manual_seed(0)
+    E, heads = 128, 4
+    counts = [5, 64, 130, 256, 2]
+    meta = ops.EdgeMeta.get(counts, dev())
+    qkv = torch.randn(meta.Rv, 3 * E, device=dev())
+    dctx = torch.randn(meta.Rv, E, device=dev())
+    ctx, lse = ops.attn_fwd(qkv, meta, E, heads)
+    dqkv = ops.attn_bwd(qkv, dctx, lse, meta, E, heads)
+    q64 = qkv.double().cpu().requires_grad_()
+    outs = []
+    off = 0
+    hd = E // heads
+    for c in counts:
+        blk = q64[off:off + c]
+        q, k, v = blk[:, :E], blk[:, E:2 * E], blk[:, 2 * E:]
+        sp = lambda t: t.reshape(c, heads, hd).transpose(0, 1)     # noqa: E731
+        s = (sp(q) / hd ** 0.5) @ sp(k).transpose(-1, -2)
+        o = torch.softmax(s, -1) @ sp(v)
+        outs.append(o.transpose(0, 1).reshape(c, E))
+        off += c
+    ref = torch.cat(outs)
+    assert H.rel_err(ctx.cpu().numpy(), ref.detach().numpy()) < 2e-5
+    (ref * dctx.double().cpu()).sum().backward()
+    assert H.rel_err(dqkv.cpu().numpy(), q64.grad.numpy()) < 1e-4

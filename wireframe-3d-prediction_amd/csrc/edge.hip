@@ -1,0 +1,338 @@
+// Edge-head data movement and the split first layer of the edge-pair MLP.
+//
+// Reference (EdgePredictor.py:117-137) gathers f[i], f[j], c[i], c[j], |c_i-c_j|
+// into an [E, 1031] matrix (134.6 MB per sample at V=256) and multiplies it by
+// edge_mlp.0.weight [512, 1031].  Splitting that weight by the concat's column
+// blocks, W = [Wa | Wb | Wc | Wd | wd], gives
+//     pre[(i,j)] = (F Wa^T + C Wc^T + b)[i] + (F Wb^T + C Wd^T)[j] + |c_i-c_j| * wd
+// i.e. two V-row GEMMs (wf3d_gemm) and the E-row *combine* below; the concat is
+// never materialised (validated to 2.5e-7 in §A.4).
+//
+// Rows are COMPACT over the batch: sample s owns vertex rows voff[s]..voff[s+1]-1
+// and edge rows eoff[s]..eoff[s+1]-1 (its V_s(V_s-1)/2 pairs in the reference's
+// lexicographic i<j order, EdgePredictor.py:83-86).
+#include "wf3d_common.h"
+
+namespace {
+
+// edge index e (lexicographic i<j over v vertices) -> (i, j)
+__device__ __forceinline__ void edge_ij(int e, int v, int& i, int& j) {
+    const float b = (float)(2 * v - 1);
+    int ii = (int)floorf((b - sqrtf(fmaxf(b * b - 8.0f * (float)e, 0.f))) * 0.5f);
+    ii = max(0, min(ii, v - 2));
+    // offset(i) = i*(2v-i-1)/2 ; fix up float rounding
+    while (ii + 1 <= v - 2 && ((ii + 1) * (2 * v - ii - 2)) / 2 <= e) ++ii;
+    while (ii > 0 && (ii * (2 * v - ii - 1)) / 2 > e) --ii;
+    i = ii;
+    j = e - (ii * (2 * v - ii - 1)) / 2 + ii + 1;
+}
+__device__ __forceinline__ int edge_offset(int i, int v) { return (i * (2 * v - i - 1)) / 2; }
+
+// ---- vertex rows: gather counts[s] leading vertices of each sample ------------
+__global__ __launch_bounds__(256) void gather_verts_kernel(const float* __restrict__ verts, long s_stride, long v_stride,
+                                                            const int32_t* __restrict__ voff,
+                                                            const int32_t* __restrict__ vsample, int Rv,
+                                                            float* __restrict__ cv) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Rv * 3) return;
+    const int r = idx / 3, k = idx % 3;
+    const int s = vsample[r];
+    cv[idx] = verts[(long)s * s_stride + (long)(r - voff[s]) * v_stride + k];
+}
+
+__global__ __launch_bounds__(256) void scatter_dverts_kernel(const float* __restrict__ dcv, const int32_t* __restrict__ voff,
+                                                              int B, int V, float* __restrict__ dverts) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * V * 3) return;
+    const int k = idx % 3, v = (idx / 3) % V, s = idx / (3 * V);
+    const int n = voff[s + 1] - voff[s];
+    dverts[idx] = v < n ? dcv[(size_t)(voff[s] + v) * 3 + k] : 0.f;
+}
+
+// ---- pair combine forward: one wave per edge row --------------------------------
+// pre[e,:] = Pa[i,:] + Pb[j,:] + delta*wd ; also LayerNorm stats of the row (the
+// wave already holds it) and delta.
+template <int NS>
+__global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__ Pa, const float* __restrict__ Pb,
+                                                        const float* __restrict__ cv, const float* __restrict__ wd,
+                                                        int wd_stride, const int32_t* __restrict__ voff,
+                                                        const int32_t* __restrict__ eoff,
+                                                        const int32_t* __restrict__ esample, int Re, int H, float eps,
+                                                        float* __restrict__ pre, float* __restrict__ mu,
+                                                        float* __restrict__ rs, float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= Re) return;
+    const int s = esample[e];
+    const int v = voff[s + 1] - voff[s];
+    int i, j;
+    edge_ij(e - eoff[s], v, i, j);
+    const int ri = voff[s] + i, rj = voff[s] + j;
+    const float dx = cv[ri * 3] - cv[rj * 3], dy = cv[ri * 3 + 1] - cv[rj * 3 + 1], dz = cv[ri * 3 + 2] - cv[rj * 3 + 2];
+    const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+    f32x4 val[NS];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int c = lane * 4 + 256 * t;
+        val[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < H) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Pa + (size_t)ri * H + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(Pb + (size_t)rj * H + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                val[t][k] = a[k] + b[k] + dl * wd[(size_t)(c + k) * wd_stride];
+                sum += val[t][k];
+            }
+            *reinterpret_cast<f32x4*>(pre + (size_t)e * H + c) = val[t];
+        }
+    }
+    const float mean = wf3d_wave_sum(sum) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int c = lane * 4 + 256 * t;
+        if (c < H) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = val[t][k] - mean; q += d * d; }
+        }
+    }
+    const float var = wf3d_wave_sum(q) / (float)H;
+    if (lane == 0) {
+        mu[e] = mean;
+        rs[e] = 1.0f / sqrtf(var + eps);
+        delta[e] = dl;
+    }
+}
+
+// ---- pair combine backward: one workgroup per vertex row --------------------------
+// dPa[v] = sum over edges with i = v of dpre[e]; dPb[v] = sum over edges with j = v;
+// dcv[v] += sum over incident edges of (dpre[e]·wd) * (c_v - c_other)/delta_e
+// (segmented reductions: no atomics)
+template <int NS>
+__global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__ dpre, const float* __restrict__ delta,
+                                                        const float* __restrict__ cv, const float* __restrict__ wd,
+                                                        int wd_stride, const int32_t* __restrict__ voff,
+                                                        const int32_t* __restrict__ eoff,
+                                                        const int32_t* __restrict__ vsample, int H,
+                                                        float* __restrict__ dPa, float* __restrict__ dPb,
+                                                        float* __restrict__ dcv) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [2][H] + [4][3]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x;
+    const int s = vsample[r];
+    const int v0 = voff[s], nv = voff[s + 1] - v0, me = r - v0;
+    const int e0 = eoff[s];
+    f32x4 wv[NS], aa[NS], ab[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int c = lane * 4 + 256 * t;
+        aa[t] = ab[t] = wv[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < H)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[t][k] = wd[(size_t)(c + k) * wd_stride];
+    }
+    const float cx = cv[r * 3], cy = cv[r * 3 + 1], cz = cv[r * 3 + 2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    // incident edges: other = 0..nv-1 except me; 4 waves interleave
+    for (int other = wave; other < nv; other += 4) {
+        if (other == me) continue;
+        const bool as_i = other > me;                       // (me, other) with me as i
+        const int e = e0 + (as_i ? edge_offset(me, nv) + (other - me - 1) : edge_offset(other, nv) + (me - other - 1));
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int c = lane * 4 + 256 * t;
+            if (c < H) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dpre + (size_t)e * H + c);
+                if (as_i) aa[t] += g; else ab[t] += g;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dot += g[k] * wv[t][k];
+            }
+        }
+        dot = wf3d_wave_sum(dot);
+        const float w = dot / delta[e];
+        const int ro = v0 + other;
+        gx += w * (cx - cv[ro * 3]); gy += w * (cy - cv[ro * 3 + 1]); gz += w * (cz - cv[ro * 3 + 2]);
+    }
+    float* ra = red;
+    float* rb = red + H;
+    float* rc = red + 2 * H;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int c = lane * 4 + 256 * t;
+                if (c < H) {
+                    f32x4 x = aa[t], y = ab[t];
+                    if (w) { x += *reinterpret_cast<f32x4*>(ra + c); y += *reinterpret_cast<f32x4*>(rb + c); }
+                    *reinterpret_cast<f32x4*>(ra + c) = x;
+                    *reinterpret_cast<f32x4*>(rb + c) = y;
+                }
+            }
+            if (lane == 0) { rc[w * 3] = gx; rc[w * 3 + 1] = gy; rc[w * 3 + 2] = gz; }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < H; c += 256) {
+        dPa[(size_t)r * H + c] = ra[c];
+        dPb[(size_t)r * H + c] = rb[c];
+    }
+    if (threadIdx.x < 3)
+        dcv[r * 3 + threadIdx.x] = (rc[threadIdx.x] + rc[3 + threadIdx.x]) + (rc[6 + threadIdx.x] + rc[9 + threadIdx.x]);
+}
+
+// ---- sigmoid + scatter into the zero-padded [B, max_E] output ---------------------
+__global__ __launch_bounds__(256) void edge_prob_fwd_kernel(const float* __restrict__ logit, const int32_t* __restrict__ eoff,
+                                                             const int32_t* __restrict__ esample, int Re, int max_e,
+                                                             float* __restrict__ probs) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Re) return;
+    const int s = esample[e];
+    probs[(size_t)s * max_e + (e - eoff[s])] = 1.0f / (1.0f + expf(-logit[e]));
+}
+__global__ __launch_bounds__(256) void edge_prob_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dprobs,
+                                                             const int32_t* __restrict__ eoff,
+                                                             const int32_t* __restrict__ esample, int Re, int max_e,
+                                                             float* __restrict__ dlogit) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Re) return;
+    const int s = esample[e];
+    const size_t o = (size_t)s * max_e + (e - eoff[s]);
+    const float p = probs[o];
+    dlogit[e] = dprobs[o] * p * (1.0f - p);
+}
+
+// ---- vertex head tail: existence sigmoid, count, and its backward -----------------
+__global__ __launch_bounds__(256) void vertex_finalize_fwd_kernel(const float* __restrict__ o, int V, int vd,
+                                                                   float* __restrict__ exist, int64_t* __restrict__ counts) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float p = 1.0f / (1.0f + expf(-o[((size_t)b * V + v) * vd + 3]));
+        exist[(size_t)b * V + v] = p;
+        mine += p > 0.5f ? 1 : 0;
+    }
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[b] = cnt;
+}
+__global__ __launch_bounds__(256) void vertex_finalize_bwd_kernel(const float* __restrict__ exist, const float* __restrict__ dexist,
+                                                                   const float* __restrict__ d_o_in, int BV, int vd,
+                                                                   float* __restrict__ d_o) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= BV * vd) return;
+    const int k = idx % vd, bv = idx / vd;
+    float g = d_o_in ? d_o_in[idx] : 0.f;
+    if (k == 3 && dexist) { const float p = exist[bv]; g += dexist[bv] * p * (1.0f - p); }
+    d_o[idx] = g;
+}
+
+}  // namespace
+
+extern "C" int wf3d_edge_gather_verts(const float* verts, long sample_stride, long vertex_stride, const int32_t* voff,
+                                      const int32_t* vsample, int Rv, float* cv, void* stream) {
+    WF3D_CHECK(Rv >= 0, WF3D_ERR_ARG, "wf3d_edge_gather_verts: bad Rv");
+    if (Rv == 0) return WF3D_OK;
+    WF3D_CHECK(verts && voff && vsample && cv, WF3D_ERR_ARG, "wf3d_edge_gather_verts: null pointer");
+    hipLaunchKernelGGL(gather_verts_kernel, dim3(wf3d_cdiv((long)Rv * 3, 256)), dim3(256), 0, (hipStream_t)stream, verts,
+                       sample_stride, vertex_stride, voff, vsample, Rv, cv);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V, float* dverts, void* stream) {
+    WF3D_CHECK(B >= 0 && V >= 0, WF3D_ERR_ARG, "wf3d_edge_scatter_dverts: bad dims");
+    if (B * V == 0) return WF3D_OK;
+    WF3D_CHECK(voff && dverts, WF3D_ERR_ARG, "wf3d_edge_scatter_dverts: null pointer");
+    hipLaunchKernelGGL(scatter_dverts_kernel, dim3(wf3d_cdiv((long)B * V * 3, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dcv, voff, B, V, dverts);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const float* wdelta,
+                                  int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample,
+                                  int Re, int H, float eps, float* pre, float* mu, float* rs, float* delta,
+                                  void* stream) {
+    WF3D_CHECK(Re >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_fwd: bad dims");
+    WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_fwd: hidden %d must be a multiple of 4, <= 2048", H);
+    if (Re == 0) return WF3D_OK;
+    WF3D_CHECK(Pa && Pb && cv && wdelta && voff && eoff && esample && pre && mu && rs && delta, WF3D_ERR_ARG,
+               "wf3d_edge_pair_fwd: null pointer");
+    const int ns = wf3d_cdiv(H, 256);
+    hipStream_t st = (hipStream_t)stream;
+#define WF3D_PF(NS_)                                                                                                 \
+    hipLaunchKernelGGL((pair_fwd_kernel<NS_>), dim3(wf3d_cdiv(Re, 4)), dim3(256), 0, st, Pa, Pb, cv, wdelta,           \
+                       wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta)
+    if (ns <= 1) WF3D_PF(1); else if (ns <= 2) WF3D_PF(2); else if (ns <= 4) WF3D_PF(4); else WF3D_PF(8);
+#undef WF3D_PF
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,
+                                  int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample,
+                                  int Rv, int H, float* dPa, float* dPb, float* dcv, void* stream) {
+    WF3D_CHECK(Rv >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: bad dims");
+    WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_bwd: hidden %d must be a multiple of 4, <= 2048", H);
+    if (Rv == 0) return WF3D_OK;
+    WF3D_CHECK(dpre && delta && cv && wdelta && voff && eoff && vsample && dPa && dPb && dcv, WF3D_ERR_ARG,
+               "wf3d_edge_pair_bwd: null pointer");
+    const int ns = wf3d_cdiv(H, 256);
+    const size_t lds = ((size_t)2 * H + 16) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define WF3D_PB(NS_)                                                                                                 \
+    hipLaunchKernelGGL((pair_bwd_kernel<NS_>), dim3(Rv), dim3(256), lds, st, dpre, delta, cv, wdelta, wdelta_stride,   \
+                       voff, eoff, vsample, H, dPa, dPb, dcv)
+    if (ns <= 1) WF3D_PB(1); else if (ns <= 2) WF3D_PB(2); else if (ns <= 4) WF3D_PB(4); else WF3D_PB(8);
+#undef WF3D_PB
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, const int32_t* esample, int Re, int max_e,
+                                  float* probs, void* stream) {
+    WF3D_CHECK(Re >= 0 && max_e >= 0, WF3D_ERR_ARG, "wf3d_edge_prob_fwd: bad dims");
+    if (Re == 0) return WF3D_OK;
+    WF3D_CHECK(logit && eoff && esample && probs, WF3D_ERR_ARG, "wf3d_edge_prob_fwd: null pointer");
+    hipLaunchKernelGGL(edge_prob_fwd_kernel, dim3(wf3d_cdiv(Re, 256)), dim3(256), 0, (hipStream_t)stream, logit, eoff,
+                       esample, Re, max_e, probs);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_edge_prob_bwd(const float* probs, const float* dprobs, const int32_t* eoff, const int32_t* esample,
+                                  int Re, int max_e, float* dlogit, void* stream) {
+    WF3D_CHECK(Re >= 0 && max_e >= 0, WF3D_ERR_ARG, "wf3d_edge_prob_bwd: bad dims");
+    if (Re == 0) return WF3D_OK;
+    WF3D_CHECK(probs && dprobs && eoff && esample && dlogit, WF3D_ERR_ARG, "wf3d_edge_prob_bwd: null pointer");
+    hipLaunchKernelGGL(edge_prob_bwd_kernel, dim3(wf3d_cdiv(Re, 256)), dim3(256), 0, (hipStream_t)stream, probs, dprobs,
+                       eoff, esample, Re, max_e, dlogit);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_vertex_finalize_fwd(const float* o, int B, int V, int vertex_dim, float* exist, int64_t* counts,
+                                        void* stream) {
+    WF3D_CHECK(B >= 0 && V > 0 && vertex_dim >= 4, WF3D_ERR_ARG, "wf3d_vertex_finalize_fwd: bad dims (vertex_dim must be >= 4)");
+    if (B == 0) return WF3D_OK;
+    WF3D_CHECK(o && exist && counts, WF3D_ERR_ARG, "wf3d_vertex_finalize_fwd: null pointer");
+    hipLaunchKernelGGL(vertex_finalize_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, o, V, vertex_dim, exist, counts);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const float* d_o_in, int B, int V,
+                                        int vertex_dim, float* d_o, void* stream) {
+    WF3D_CHECK(B >= 0 && V > 0 && vertex_dim >= 4, WF3D_ERR_ARG, "wf3d_vertex_finalize_bwd: bad dims");
+    if (B == 0) return WF3D_OK;
+    WF3D_CHECK(exist && d_o, WF3D_ERR_ARG, "wf3d_vertex_finalize_bwd: null pointer");
+    hipLaunchKernelGGL(vertex_finalize_bwd_kernel, dim3(wf3d_cdiv((long)B * V * vertex_dim, 256)), dim3(256), 0,
+                       (hipStream_t)stream, exist, dexist, d_o_in, B * V, vertex_dim, d_o);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}

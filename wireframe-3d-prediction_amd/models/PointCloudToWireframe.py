@@ -1,0 +1,62 @@
+"""Drop-in `models.PointCloudToWireframe.PointCloudToWireframe` (reference
+models/PointCloudToWireframe.py:10-121) on the MI355X HIP path.
+
+Differences in HOW, not WHAT: point_features is pooled once for both heads, and
+the edge head runs all samples of the batch in one ragged pass instead of a
+Python loop of batch-1 calls with a device->host sync each.  Outputs (keys,
+shapes, dtypes, zero padding, edge_indices list-of-lists) are the reference's."""
+import torch
+import torch.nn as nn
+
+from models.EdgePredictor import EdgePredictor
+from models.PointNetEncoder import PointNetEncoder
+from models.VertexPredictor import VertexPredictor
+from wf3d.functional import edge_index_lists
+
+
+class PointCloudToWireframe(nn.Module):
+    def __init__(self, input_dim=8, max_vertices=64):
+        super().__init__()
+        self.max_vertices = max_vertices
+        self.encoder = PointNetEncoder(input_dim=input_dim)
+        self.vertex_predictor = VertexPredictor(global_feature_dim=512, max_vertices=max_vertices)
+        self.edge_predictor = EdgePredictor(vertex_dim=3)
+        self._count_cache = (None, None)
+
+    def set_dropout(self, p):
+        """Set every dropout probability of the edge head (the only non-zero ones)."""
+        ep = self.edge_predictor
+        ep.vertex_proj[5].p = ep.edge_mlp[3].p = ep.edge_mlp[7].p = float(p)
+        ep.attention.dropout = float(p)
+        return self
+
+    def _host_counts(self, t):
+        """Vertex counts as Python ints.  One device->host read (the reference does
+        one `.item()` per sample, :80/:90); the read is skipped when the same
+        unmodified tensor is passed again, as train.py does every step."""
+        if not t.is_cuda:
+            return [int(c) for c in t.tolist()]
+        key = (t.data_ptr(), t._version, t.numel())
+        if self._count_cache[0] == key:
+            return self._count_cache[1]
+        vals = [int(c) for c in t.tolist()]
+        self._count_cache = (key, vals)
+        return vals
+
+    def forward(self, point_cloud, target_vertex_counts=None):
+        g, _pf, pooled_mean, pooled_max = self.encoder.encode(point_cloud)
+        vo = self.vertex_predictor.predict(g, pooled_mean, pooled_max)
+        verts = vo["vertices"]
+        if self.training and target_vertex_counts is not None:
+            counts = self._host_counts(target_vertex_counts)          # ground-truth counts (:77-86)
+        else:
+            counts = [int(c) for c in vo["actual_vertex_counts"].tolist()]   # data-dependent (:87-97)
+        v = self.max_vertices
+        counts = [min(c, v) if c >= 0 else max(v + c, 0) for c in counts]    # what `[:count]` slicing does
+        probs = self.edge_predictor.forward_ragged(verts, counts)
+        return {"vertices": verts,
+                "existence_probabilities": vo["existence_probabilities"],
+                "edge_probs": probs,
+                "edge_indices": edge_index_lists(counts),
+                "global_features": g,
+                "actual_vertex_counts": vo["actual_vertex_counts"]}

@@ -49,7 +49,7 @@ def scratch(nbytes, device, slot=0):
 
 
 def _rows2d(t):
-    if t.dim() != 2 or t.stride(1) != 1:
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise RuntimeError("wf3d: expected a 2-D tensor with unit inner stride")
     return t
 
@@ -214,3 +214,149 @@ def pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct,
     check(_lib.load().wf3d_pool4_bwd(_p(valid), _p(cnt), _p(arg_m), _p(arg_u), _p(dmmax), _p(dmavg), _p(dumean),
                                      _p(dumax), _p(dpf_direct), B, N, C, _p(dpf), _stream()), "pool4_bwd")
     return dpf
+
+
+# ---------------------------------------------------------------------------
+# vertex-head tail and edge head
+# ---------------------------------------------------------------------------
+def vertex_finalize_fwd(o, V, vd):
+    _need_cuda(o)
+    B = o.shape[0]
+    exist = torch.empty(B, V, dtype=torch.float32, device=o.device)
+    counts = torch.empty(B, dtype=torch.int64, device=o.device)
+    check(_lib.load().wf3d_vertex_finalize_fwd(_p(o), B, V, vd, _p(exist), _p(counts), _stream()), "vertex_finalize_fwd")
+    return exist, counts
+
+
+def vertex_finalize_bwd(exist, dexist, d_o_in, B, V, vd):
+    _need_cuda(exist, dexist, d_o_in)
+    for t in (dexist, d_o_in):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("wf3d.vertex_finalize_bwd: contiguous cotangents required")
+    d_o = torch.empty(B, V * vd, dtype=torch.float32, device=exist.device)
+    check(_lib.load().wf3d_vertex_finalize_bwd(_p(exist), _p(dexist), _p(d_o_in), B, V, vd, _p(d_o), _stream()),
+          "vertex_finalize_bwd")
+    return d_o
+
+
+class EdgeMeta:
+    """Compact ragged row layout of one batch: sample s owns vertex rows
+    voff[s]..voff[s+1]-1 and edge rows eoff[s]..eoff[s+1]-1."""
+    _cache = {}
+
+    def __init__(self, counts, device):
+        self.counts = tuple(int(c) for c in counts)
+        self.B = len(self.counts)
+        ecount = [c * (c - 1) // 2 for c in self.counts]
+        voff, eoff = [0], [0]
+        for c, e in zip(self.counts, ecount):
+            voff.append(voff[-1] + c)
+            eoff.append(eoff[-1] + e)
+        self.Rv, self.Re = voff[-1], eoff[-1]
+        self.vmax = max(self.counts, default=0)
+        self.max_e = max(ecount, default=0)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.voff = torch.tensor(voff, **i32)
+        self.eoff = torch.tensor(eoff, **i32)
+        sid = torch.arange(self.B, **i32)
+        self.vsample = torch.repeat_interleave(sid, torch.tensor(self.counts, dtype=torch.int64, device=device))
+        self.esample = torch.repeat_interleave(sid, torch.tensor(ecount, dtype=torch.int64, device=device))
+
+    @classmethod
+    def get(cls, counts, device):
+        key = (device.index, tuple(int(c) for c in counts))
+        m = cls._cache.get(key)
+        if m is None:
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            m = cls._cache[key] = cls(counts, device)
+        return m
+
+
+def edge_gather_verts(verts, meta):
+    """verts [B, V, 3] (any strides with unit inner stride) -> cv [Rv, 3]."""
+    _need_cuda(verts)
+    if verts.stride(2) != 1:
+        raise RuntimeError("wf3d.edge_gather_verts: inner stride must be 1")
+    cv = torch.empty(meta.Rv, 3, dtype=torch.float32, device=verts.device)
+    check(_lib.load().wf3d_edge_gather_verts(_p(verts), verts.stride(0), verts.stride(1), _p(meta.voff),
+                                             _p(meta.vsample), meta.Rv, _p(cv), _stream()), "edge_gather_verts")
+    return cv
+
+
+def edge_scatter_dverts(dcv, meta, B, V):
+    out = torch.empty(B, V, 3, dtype=torch.float32, device=dcv.device)
+    check(_lib.load().wf3d_edge_scatter_dverts(_p(dcv), _p(meta.voff), B, V, _p(out), _stream()), "edge_scatter_dverts")
+    return out
+
+
+def attn_fwd(qkv, meta, E, heads, drop_p=0.0, seed=0):
+    _need_cuda(qkv)
+    ctx = torch.empty(meta.Rv, E, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(meta.Rv, heads, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().wf3d_attn_fwd(_p(qkv), _p(meta.voff), meta.B, meta.vmax, E, heads, float(drop_p),
+                                    int(seed) & 0xFFFFFFFF, _p(ctx), _p(lse), _stream()), "attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(qkv, dctx, lse, meta, E, heads, drop_p=0.0, seed=0):
+    _need_cuda(qkv, dctx, lse)
+    if not dctx.is_contiguous():
+        raise RuntimeError("wf3d.attn_bwd: contiguous dctx required")
+    dqkv = torch.empty_like(qkv)
+    check(_lib.load().wf3d_attn_bwd(_p(qkv), _p(dctx), _p(lse), _p(meta.voff), meta.B, meta.vmax, E, heads,
+                                    float(drop_p), int(seed) & 0xFFFFFFFF, _p(dqkv), _stream()), "attn_bwd")
+    return dqkv
+
+
+def _wdelta(W0, H):
+    if tuple(W0.shape) != (H, 2 * H + 7) or not W0.is_contiguous():
+        raise RuntimeError("wf3d: edge_mlp.0.weight must be contiguous [H, 2H+7]")
+    return W0[:, 2 * H + 6], W0.stride(0)
+
+
+def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS):
+    _need_cuda(Pa, Pb, cv, W0)
+    H = Pa.shape[1]
+    wd, stride = _wdelta(W0, H)
+    dev = Pa.device
+    pre = torch.empty(meta.Re, H, dtype=torch.float32, device=dev)
+    mu = torch.empty(meta.Re, dtype=torch.float32, device=dev)
+    rs = torch.empty(meta.Re, dtype=torch.float32, device=dev)
+    delta = torch.empty(meta.Re, dtype=torch.float32, device=dev)
+    check(_lib.load().wf3d_edge_pair_fwd(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
+                                         _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
+                                         _stream()), "edge_pair_fwd")
+    return pre, mu, rs, delta
+
+
+def edge_pair_bwd(dpre, delta, cv, W0, meta):
+    _need_cuda(dpre, delta, cv, W0)
+    H = dpre.shape[1]
+    wd, stride = _wdelta(W0, H)
+    dev = dpre.device
+    dPa = torch.empty(meta.Rv, H, dtype=torch.float32, device=dev)
+    dPb = torch.empty(meta.Rv, H, dtype=torch.float32, device=dev)
+    dcv = torch.empty(meta.Rv, 3, dtype=torch.float32, device=dev)
+    check(_lib.load().wf3d_edge_pair_bwd(_p(dpre), _p(delta), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
+                                         _p(meta.vsample), meta.Rv, H, _p(dPa), _p(dPb), _p(dcv), _stream()),
+          "edge_pair_bwd")
+    return dPa, dPb, dcv
+
+
+def edge_prob_fwd(logit, meta):
+    _need_cuda(logit)
+    probs = torch.zeros(meta.B, meta.max_e, dtype=torch.float32, device=logit.device)   # padding is exactly 0.0
+    check(_lib.load().wf3d_edge_prob_fwd(_p(logit), _p(meta.eoff), _p(meta.esample), meta.Re, meta.max_e, _p(probs),
+                                         _stream()), "edge_prob_fwd")
+    return probs
+
+
+def edge_prob_bwd(probs, dprobs, meta):
+    _need_cuda(probs, dprobs)
+    if not dprobs.is_contiguous():
+        raise RuntimeError("wf3d.edge_prob_bwd: contiguous dprobs required")
+    dlogit = torch.empty(meta.Re, 1, dtype=torch.float32, device=probs.device)
+    check(_lib.load().wf3d_edge_prob_bwd(_p(probs), _p(dprobs), _p(meta.eoff), _p(meta.esample), meta.Re, meta.max_e,
+                                         _p(dlogit), _stream()), "edge_prob_bwd")
+    return dlogit
