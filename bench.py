@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: point-clouds/sec, forward+backward, synthetic
+N=4096x8 clouds (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = PointCloudToWireframe forward (train mode, the reference's dropout
+p=0.1 active, counts = V for every sample) + backward from a fixed random
+cotangent on (vertices, existence_probabilities, edge_probs) [+ the RCCL
+gradient all-reduce when N > 1].  Inputs and parameters are resident in HBM
+before the timed region; no optimizer step, no Hungarian loss.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "wireframe-3d-prediction_amd"))
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (per-GPU batch, N, V)
+    "cfg2": (32, 4096, 64),
+    "cfg4": (8, 16384, 64),
+    "cfg5": (32, 4096, 256),
+    "cfg1": (1, 1024, 32),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, chip-level parameters
+SEED = 1234
+
+
+def algorithmic_flops_per_cloud(N, V, hidden=(512, 1024, 2048, 1024), out=512, din=8):
+    """Reference-formulation FLOPs of fwd+bwd per cloud:
+    MAC x 2, backward = 2 x forward."""
+    dims = [din] + list(hidden) + [out]
+    enc = N * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    fusion = 1024 * 2048 + 2048 * 1024 + 1024 * 512
+    vert = 1024 * 512 + 512 * 4096 + 4096 * 2048 + 2048 * 2048 + 2048 * 1024 + 1024 * 4 * V + 512 * 2048 + 512 * 1024
+    E = V * (V - 1) // 2
+    edge = V * (3 * 256 + 256 * 512 + 512 * 1536 + 512 * 512) + 2 * V * V * 512 \
+        + E * (1031 * 512 + 512 * 256 + 256 * 128 + 128)
+    return 6 * (enc + fusion + vert + edge), 6 * enc
+
+
+def make_inputs(B, N, V, rank, device):
+    g = torch.Generator().manual_seed(SEED + 7919 * rank)     # per global sample shard
+    x = torch.randn(B, N, 8, generator=g)
+    counts = torch.full((B,), V, dtype=torch.long)
+    E = V * (V - 1) // 2
+    cot = {"vertices": torch.randn(B, V, 3, generator=g),
+           "existence_probabilities": torch.randn(B, V, generator=g),
+           "edge_probs": torch.randn(B, E, generator=g)}
+    return x.to(device), counts.to(device), {k: v.to(device) for k, v in cot.items()}
+
+
+class GemmTimer:
+    """HIP-event timing of the dominant kernel's launches (the 128x128 fp32-MFMA
+    GEMM tile of wf3d_gemm) inside the timed region, on the stream they are
+    launched on (torch's current stream)."""
+
+    def __init__(self, min_flops):
+        self.min_flops, self.recs = min_flops, []
+
+    def install(self, ops):
+        self._orig = ops.gemm
+        timer = self
+
+        def timed(a, b, layout, **kw):
+            if layout == ops.TN:
+                K, M = a.shape; N = b.shape[1]
+            elif layout == ops.NN:
+                M, K = a.shape; N = b.shape[1]
+            else:
+                M, K = a.shape; N = b.shape[0]
+            fl = 2.0 * M * N * K
+            if fl < timer.min_flops:
+                return timer._orig(a, b, layout, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = timer._orig(a, b, layout, **kw)
+            e1.record()
+            timer.recs.append((e0, e1, fl))
+            return out
+
+        ops.gemm = timed
+        import wf3d.functional as F
+        F.ops.gemm = timed
+
+    def uninstall(self, ops):
+        ops.gemm = self._orig
+
+    def summary(self):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.recs)
+        fl = sum(f for _, _, f in self.recs)
+        return len(self.recs), ms, fl
+
+
+def cpu_baseline(model, N, V, seconds_budget=25.0):
+    """The CPU oracle (oracle/reference_cpu.py, proven equal to the reference in
+    the build container) timed on this box's host cores on a bounded sample of
+    the same workload: cfg2 shape at batch 4, 1 warm-up + up to 3 timed steps."""
+    from oracle import reference_cpu as oracle
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    Bc = 4
+    P = oracle.params_from_module(model)
+    g = torch.Generator().manual_seed(SEED)
+    x = torch.randn(Bc, N, 8, generator=g)
+    counts = torch.full((Bc,), V, dtype=torch.long)
+    E = V * (V - 1) // 2
+    cot = {"vertices": torch.randn(Bc, V, 3, generator=g), "existence_probabilities": torch.randn(Bc, V, generator=g),
+           "edge_probs": torch.randn(Bc, E, generator=g)}
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        for p in P.values():
+            p.grad = None
+        t0 = time.time()
+        out = oracle.model_forward(P, x, counts, V, training=True)
+        sum((out[k] * cot[k]).sum() for k in cot).backward()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and times:
+            break
+    med = statistics.median(times)
+    return {"value": Bc / med, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/reference_cpu.py fwd+bwd, cfg2 shape N={N} V={V} at batch {Bc}, "
+                      f"1 warm-up + {len(times)} timed steps, median {med * 1e3:.0f} ms/step, dropout 0"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    args = ap.parse_args()
+
+    from wf3d import dist as wd
+    from wf3d import ops
+    from models.PointCloudToWireframe import PointCloudToWireframe
+
+    rank, world, device = wd.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    B, N, V = CONFIGS[args.config]
+
+    torch.manual_seed(SEED)
+    model = PointCloudToWireframe(input_dim=8, max_vertices=V).to(device)
+    model.vertex_predictor.ensure_point_pool_proj(1024, device)       # lazy layer, identical on every rank
+    wd.sync_parameters(model)
+    model.set_dropout(args.dropout)
+    model.train()
+    reducer = wd.GradReducer(model) if world > 1 else None
+    x, counts, cot = make_inputs(B, N, V, rank, device)
+    inv = 1.0 / (B * world)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(x, counts)
+        loss = sum((out[k] * cot[k]).sum() for k in cot) * inv
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = GemmTimer(min_flops=2.0 * 128 * 128 * 4096 * 64)
+    timer.install(ops)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.uninstall(ops)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        n_launch, gemm_ms, gemm_fl = timer.summary()
+        total_fl, enc_fl = algorithmic_flops_per_cloud(N, V)
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get("gemm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "point-clouds/sec fwd+bwd",
+            "value": B * world * args.steps / dt,
+            "unit": "clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: N={N}x8 clouds, max_vertices={V}, batch {B}/GPU, train-mode fwd+bwd, "
+                                   f"edge-head dropout p={args.dropout}, counts=V",
+                       "global_batch": B * world, "num_points": N, "max_vertices": V,
+                       "parallelism": f"dp{world}", "algorithmic_gflop_per_cloud": total_fl / 1e9},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "gemm_kernel<2,2,2,2> (128x128x32 v_mfma_f32_32x32x2_f32)",
+                         "launches_timed": n_launch, "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
+                         "whole_step_tflops": total_fl * B * world * args.steps / dt / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model, N, V)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

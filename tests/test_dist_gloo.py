@@ -1,0 +1,120 @@
+"""world_size-2 CPU (gloo) tests of the data-parallel gradient path: the
+bucketed reducer must give every rank the mean of the per-rank gradients, launch
+buckets in backward order, survive a lazily created parameter and parameters
+that never get a gradient, and shard the batch contiguously."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H  # noqa: F401
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class Toy(torch.nn.Module):
+    """Parameter names mimic the model's stages so bucket ordering is exercised."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.ModuleDict({"mlp": torch.nn.Linear(6, 5), "feature_fusion": torch.nn.Linear(5, 4)})
+        self.vertex_predictor = torch.nn.Linear(4, 3)
+        self.edge_predictor = torch.nn.ModuleDict({"used": torch.nn.Linear(3, 2), "spatial_proj": torch.nn.Linear(3, 2)})
+
+    def forward(self, x):
+        h = torch.relu(self.encoder["mlp"](x))
+        h = torch.relu(self.encoder["feature_fusion"](h))
+        return self.edge_predictor["used"](torch.tanh(self.vertex_predictor(h)))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from wf3d import dist as wd
+    r, w, dev = wd.init_from_env("cpu")
+    assert (r, w) == (rank, world) and dev.type == "cpu"
+    torch.manual_seed(100 + rank)                    # different init per rank on purpose
+    m = Toy()
+    wd.sync_parameters(m)
+    ref = [p.detach().clone() for p in m.parameters()]
+    gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
+    dist.all_gather(gathered, ref[0])
+    assert all(torch.equal(g, gathered[0]) for g in gathered)        # broadcast worked
+    red = wd.GradReducer(m, bucket_mb=1e-4)                           # tiny buckets -> several
+    stages = [wd._stage_of(n) for b in red._buckets for n, p in m.named_parameters() if p is b["params"][0]]
+    assert stages == sorted(stages)                                   # edge -> vertex -> fusion -> mlp
+    torch.manual_seed(7)
+    X = torch.randn(8, 6)
+    lo, hi = wd.shard_batch(8, rank, world)
+    for step in range(3):
+        if step == 2:                                                  # lazily created parameter appears
+            m.late = torch.nn.Linear(2, 1)
+            wd.sync_parameters(m)
+        m.zero_grad()
+        out = m(X[lo:hi])
+        loss = out.sum() if step < 2 else m.late(out).sum()
+        loss.backward()
+        red.finish()
+        # expected: mean over ranks of the local gradients == grad of the mean loss over shards
+        m2 = Toy()
+        m2.load_state_dict({k: v for k, v in m.state_dict().items() if not k.startswith("late")})
+        tot = None
+        for rr in range(world):
+            a, b = wd.shard_batch(8, rr, world)
+            o = m2(X[a:b])
+            l = o.sum() if step < 2 else m.late(o).sum()
+            tot = l if tot is None else tot + l
+        m2.zero_grad()
+        if step == 2:
+            m.late.zero_grad()
+        exp = torch.autograd.grad(tot / world, [p for n, p in m2.named_parameters() if "spatial" not in n])
+        got = [p.grad for n, p in m.named_parameters() if "spatial" not in n and not n.startswith("late")]
+        for g, e in zip(got, exp):
+            assert torch.allclose(g, e, atol=1e-6), (step, (g - e).abs().max())
+        assert m.edge_predictor["spatial_proj"].weight.grad is None
+    q.put((rank, "ok", red.bucket_summary()))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    res = []
+    while not q.empty():
+        res.append(q.get())
+    for p in procs:
+        assert p.exitcode == 0, f"worker exit {p.exitcode}"
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] == "ok" for r in res)
+    assert len(res[0][2]) >= 4
+
+
+def test_shard_batch():
+    from wf3d import dist as wd
+    assert [wd.shard_batch(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    with pytest.raises(ValueError):
+        wd.shard_batch(10, 0, 4)
+
+
+def test_single_process_reducer_is_noop():
+    from wf3d import dist as wd
+    m = Toy()
+    red = wd.GradReducer(m)
+    m(torch.randn(4, 6)).sum().backward()
+    g = m.vertex_predictor.weight.grad.clone()
+    red.finish()
+    assert torch.equal(g, m.vertex_predictor.weight.grad)
