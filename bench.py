@@ -102,16 +102,36 @@ class GemmTimer:
         return len(self.recs), ms, fl
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup
+    CPU quota (a 1-GPU box gives a 16-core share of a 256-thread host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, int(os.environ.get("WF3D_CPU_THREADS", "16")))
+
+
 def cpu_baseline(model, N, V, seconds_budget=25.0):
     """The CPU oracle (oracle/reference_cpu.py, proven equal to the reference in
     the build container) timed on this box's host cores on a bounded sample of
     the same workload: cfg2 shape at batch 4, 1 warm-up + up to 3 timed steps."""
     from oracle import reference_cpu as oracle
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     Bc = 4
     P = oracle.params_from_module(model)

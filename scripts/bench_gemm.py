@@ -1,0 +1,48 @@
+"""Micro-benchmark of wf3d_gemm at the encoder's shapes (cfg2: M = 32*4096 rows).
+Interleaved rounds in one process, random data, median per shape (TFLOP/s)."""
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wireframe-3d-prediction_amd"))
+import torch  # noqa: E402
+from wf3d import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+M = int(os.environ.get("M", 131072))
+layers = [(512, 1024), (1024, 2048), (2048, 1024), (1024, 512)]   # (K_in, N_out)
+torch.manual_seed(0)
+cases = []
+for K, N in layers:
+    X = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) * 0.05
+    G = torch.randn(M, N, device=dev)
+    mu, rs = ops.row_stats(X)
+    gam, bet = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+    pro = ops.Pro(ops.ACT_RELU, mu, rs, gam, bet)
+    o_nt, o_nn, o_tn = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+    fl = 2.0 * M * N * K
+    cases.append((f"NT+pro K={K} N={N}", lambda X=X, W=W, pro=pro, o=o_nt: ops.gemm(X, W, ops.NT, pro=pro, out=o), fl))
+    cases.append((f"NT     K={K} N={N}", lambda X=X, W=W, o=o_nt: ops.gemm(X, W, ops.NT, out=o), fl))
+    cases.append((f"NN     K={N} N={K}", lambda G=G, W=W, o=o_nn: ops.gemm(G, W, ops.NN, out=o), fl))
+    cases.append((f"TN+pro K={M} out={N}x{K}", lambda G=G, X=X, pro=pro, o=o_tn: ops.gemm(G, X, ops.TN, pro=pro, out=o), fl))
+times = {c[0]: [] for c in cases}
+for c in cases:
+    c[1]()
+torch.cuda.synchronize()
+for r in range(5):
+    for name, fn, fl in cases:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times[name].append(e0.elapsed_time(e1))
+tot = 0.0
+for name, fn, fl in cases:
+    ms = statistics.median(times[name])
+    if not name.startswith("NT  "):
+        tot += ms
+    print(f"{name:34s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
+print(f"sum (NT+pro, NN, TN+pro) = {tot:.2f} ms")

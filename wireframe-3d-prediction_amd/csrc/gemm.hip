@@ -40,7 +40,7 @@ struct GemmParams {
     int accumulate;
     int ksplit, kt_per_split;
     float* slab;
-    int vecA, vecB;
+    int vecA, vecB, vecP;
     int nbm, nbn;
 };
 
@@ -129,33 +129,39 @@ __device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int ks, in
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+// branch-free staging loads for tiles that are completely inside the matrices
+template <int ROWS, bool KC>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ p0, int ld, int k0, f32x4 (&v)[ROWS / 32]) {
+    constexpr int NV = ROWS / 32;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p0 + (size_t)(32 * i) * ld + k0);
+    } else {
+        constexpr int KPP = 256 / (ROWS / 4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p0 + (size_t)(k0 + KPP * i) * ld);
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool FAST>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int m0, int n0, int kt0, int kt1) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
     constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
     constexpr int NVA = BM / 32, NVB = BN / 32;
     constexpr bool PRO_A = PRO && A_KC;     // NT: activation operand is A [M,K]
     constexpr bool PRO_B = PRO && !A_KC;    // TN: activation operand is B [K,N]
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    constexpr int TPRB = BN / 4, KPPB = 256 / TPRB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int h = lane >> 5, l31 = lane & 31;
 
-    // XCD-aware tile order: blocks bid, bid+8, ... share an XCD (round-robin
-    // dispatch); give each XCD a contiguous run of tiles, column tiles fastest,
-    // so the A row-panel of a tile row is fetched into ONE L2 (bijective form,
-    // cdna_hip_programming.md T1).
-    const int nwg = p.nbm * p.nbn;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int m0 = (vid / p.nbn) * BM, n0 = (vid % p.nbn) * BN;
-
-    const int ktotal = (p.K + BK - 1) / BK;
-    const int kt0 = blockIdx.z * p.kt_per_split;
-    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+    // per-thread staging base pointers (FAST path)
+    const float* pa0 = A_KC ? p.A + (size_t)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 4
+                            : p.A + (size_t)(tid / (BM / 4)) * p.lda + m0 + (tid % (BM / 4)) * 4;
+    const float* pb0 = B_KC ? p.B + (size_t)(n0 + (tid >> 3)) * p.ldb + (tid & 7) * 4
+                            : p.B + (size_t)(tid / TPRB) * p.ldb + n0 + (tid % TPRB) * 4;
 
     // loop-invariant prologue parameters
     float mu_a[NVA], rs_a[NVA];
@@ -170,50 +176,70 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
     }
     if (PRO_B && p.has_affine) {
-        const int gcol = n0 + (tid % (BN / 4)) * 4;
+        const int gcol = n0 + (tid % TPRB) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (gcol + j < p.N) { gam_b[j] = p.pgam[gcol + j]; bet_b[j] = p.pbet[gcol + j]; }
     }
 
     f32x4 ra[NVA], rb[NVB];
+    f32x4 pg = {1.f, 1.f, 1.f, 1.f}, pbv = {0.f, 0.f, 0.f, 0.f};   // PRO_A: gamma/beta of this tile's k columns
+    float mu_b[NVB], rs_b[NVB];                                     // PRO_B: stats of this tile's k rows
     auto fetch = [&](int kt) {
-        load_tile<BM, A_KC>(p.A, p.lda, m0, p.M, kt * BK, p.K, p.vecA, tid, ra);
-        load_tile<BN, B_KC>(p.B, p.ldb, n0, p.N, kt * BK, p.K, p.vecB, tid, rb);
+        const int k0 = kt * BK;
+        if (FAST) {
+            load_tile_fast<BM, A_KC>(pa0, p.lda, k0, ra);
+            load_tile_fast<BN, B_KC>(pb0, p.ldb, k0, rb);
+        } else {
+            load_tile<BM, A_KC>(p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid, ra);
+            load_tile<BN, B_KC>(p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid, rb);
+        }
+        if (PRO_A && p.has_affine) {
+            const int k = k0 + (tid & 7) * 4;
+            if (FAST) {
+                pg = *reinterpret_cast<const f32x4*>(p.pgam + k);
+                pbv = *reinterpret_cast<const f32x4*>(p.pbet + k);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pg[j] = k + j < p.K ? p.pgam[k + j] : 1.f;
+                    pbv[j] = k + j < p.K ? p.pbet[k + j] : 0.f;
+                }
+            }
+        }
+        if (PRO_B) {
+#pragma unroll
+            for (int i = 0; i < NVB; ++i) {
+                const int k = k0 + tid / TPRB + KPPB * i;          // = row of the activation matrix
+                const bool ok = p.has_ln && (FAST || k < p.K);
+                mu_b[i] = ok ? p.pmu[k] : 0.f;
+                rs_b[i] = ok ? p.prs[k] : 1.f;
+            }
+        }
     };
     auto commit = [&](int kt, int stage) {
         float* As = smem + stage * (A_SZ + B_SZ);
         float* Bs = As + A_SZ;
         if (PRO_A) {
             const int k = kt * BK + (tid & 7) * 4;
-            f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (p.has_affine) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k + j < p.K) { g[j] = p.pgam[k + j]; b[j] = p.pbet[k + j]; }
-            }
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
                 const int grow = m0 + (tid >> 3) + 32 * i;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    ra[i][j] = pro_one<ACT>(ra[i][j], mu_a[i], rs_a[i], g[j], b[j], p, grow, k + j,
-                                            grow < p.M && k + j < p.K);
+                    ra[i][j] = pro_one<ACT>(ra[i][j], mu_a[i], rs_a[i], pg[j], pbv[j], p, grow, k + j,
+                                            FAST || (grow < p.M && k + j < p.K));
             }
         }
         if (PRO_B) {
-            constexpr int TPR = BN / 4, KPP = 256 / TPR;
-            const int gcol = n0 + (tid % TPR) * 4;
+            const int gcol = n0 + (tid % TPRB) * 4;
 #pragma unroll
             for (int i = 0; i < NVB; ++i) {
-                const int k = kt * BK + tid / TPR + KPP * i;     // = row of the activation matrix
-                const bool okr = k < p.K;
-                const float mu = (p.has_ln && okr) ? p.pmu[k] : 0.f;
-                const float rs = (p.has_ln && okr) ? p.prs[k] : 1.f;
+                const int k = kt * BK + tid / TPRB + KPPB * i;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    rb[i][j] = pro_one<ACT>(rb[i][j], mu, rs, gam_b[j], bet_b[j], p, k, gcol + j,
-                                            okr && gcol + j < p.N);
+                    rb[i][j] = pro_one<ACT>(rb[i][j], mu_b[i], rs_b[i], gam_b[j], bet_b[j], p, k, gcol + j,
+                                            FAST || (k < p.K && gcol + j < p.N));
             }
         }
         store_tile<BM, A_KC>(As, tid, ra);
@@ -286,6 +312,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             }
         }
     }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
+    constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    // XCD-aware tile order: blocks bid, bid+8, ... share an XCD (round-robin
+    // dispatch); give each XCD a contiguous run of tiles, column tiles fastest,
+    // so the A row-panel of a tile row is fetched into ONE L2 (bijective form,
+    // cdna_hip_programming.md T1).
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * BM, n0 = (vid % p.nbn) * BN;
+
+    const int ktotal = (p.K + BK - 1) / BK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    // FAST: every staged tile of this workgroup lies fully inside A and B and is
+    // 16-B loadable -> branch-free staging (block-uniform choice)
+    const bool fast = p.vecA && p.vecB && p.vecP && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (kt1 * BK <= p.K);
+    if (fast) gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, true>(p, smem, m0, n0, kt0, kt1);
+    else      gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, false>(p, smem, m0, n0, kt0, kt1);
 }
 
 // split-K combine: deterministic slab sum + epilogue terms
@@ -375,6 +429,7 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     p.accumulate = d->accumulate;
     p.vecA = ((uintptr_t)d->A % 16 == 0) && (d->lda % 4 == 0);
     p.vecB = ((uintptr_t)d->B % 16 == 0) && (d->ldb % 4 == 0);
+    p.vecP = !p.has_affine || (((uintptr_t)d->pro_gamma % 16 == 0) && ((uintptr_t)d->pro_beta % 16 == 0));
 
     const bool small = d->layout != WF3D_TN && small_m(d->M);
     const int bm = small ? 32 : 128, bn = 128;
