@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 CSVs that a gpurun call left under gpurun_out/ into the
+committed summaries under profiles/ (round-tagged), and into
+profiles/pmc_summary.json, which bench.py reads for `roofline.traffic`.
+
+    python scripts/summarize_profiles.py r01
+
+Inputs (written on the GPU box by the commands recorded in profiles/README.md):
+    gpurun_out/prof_<tag>_trace*/**/_kernel_stats.csv   rocprofv3 --kernel-trace --stats
+    gpurun_out/prof_<tag>_fetch/**/_counter_collection.csv   --pmc FETCH_SIZE      (own pass)
+    gpurun_out/prof_<tag>_write/**/_counter_collection.csv   --pmc WRITE_SIZE      (own pass)
+    gpurun_out/prof_<tag>_sq/**/_counter_collection.csv      --pmc SQ_* GRBM_GUI_ACTIVE
+
+HBM-byte corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane coalesced
+loads, which is how the GEMM stages both operands -> read bytes = 2 x FETCH_SIZE x 1024.
+WRITE_SIZE is exact for the 4-B-per-lane / 16-B-per-lane stores used here.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def one(pattern):
+    fs = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
+    return fs[-1] if fs else None
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:70]
+
+
+# ---- kernel-trace stats -------------------------------------------------------
+ks = one(f"prof_{tag}_trace*/**/*_kernel_stats.csv")
+stats_rows = []
+if ks:
+    shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(ks)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    for r in rows:
+        stats_rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
+                           float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+
+
+def pmc(pattern):
+    f = one(pattern)
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return out
+    for r in csv.DictReader(open(f)):
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        out[short(r["Kernel_Name"])][r["Counter_Name"]].append((float(r["Counter_Value"]), dur, int(r["Dispatch_Id"])))
+    return out
+
+
+fetch, write, sq = pmc(f"prof_{tag}_fetch/**/*_counter_collection.csv"), \
+    pmc(f"prof_{tag}_write/**/*_counter_collection.csv"), pmc(f"prof_{tag}_sq/**/*_counter_collection.csv")
+
+BIG_US = 800.0          # the encoder's twelve >=137-GFLOP GEMM launches per step all run > 1 ms
+
+
+def big(vals):
+    return [v for v, d, _ in vals if d >= BIG_US]
+
+
+summary = {"tag": tag, "kernels": {}}
+gemm_fetch, gemm_write = [], []
+for name in sorted(set(fetch) | set(write)):
+    fv = fetch.get(name, {}).get("FETCH_SIZE", [])
+    wv = write.get(name, {}).get("WRITE_SIZE", [])
+    e = {"launches": len(fv) or len(wv)}
+    if fv:
+        e["read_bytes_avg"] = 2 * 1024 * sum(v for v, _, _ in fv) / len(fv)
+    if wv:
+        e["write_bytes_avg"] = 1024 * sum(v for v, _, _ in wv) / len(wv)
+    summary["kernels"][name] = e
+    if name.startswith("gemm_kernel<2, 2, 2, 2"):
+        gemm_fetch += big(fv)
+        gemm_write += big(wv)
+mfma = {}
+for name, ctrs in sq.items():
+    if not name.startswith("gemm_kernel<2, 2, 2, 2"):
+        continue
+    busy = sum(v for v, d, _ in ctrs.get("SQ_VALU_MFMA_BUSY_CYCLES", []) if d >= BIG_US)
+    gui = sum(v for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []) if d >= BIG_US)
+    waves = sum(v for v, d, _ in ctrs.get("SQ_WAVE_CYCLES", []) if d >= BIG_US)
+    sqb = sum(v for v, d, _ in ctrs.get("SQ_BUSY_CYCLES", []) if d >= BIG_US)
+    mops = sum(v for v, d, _ in ctrs.get("SQ_INSTS_VALU_MFMA_MOPS_F32", []) if d >= BIG_US)
+    n = len([1 for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []) if d >= BIG_US])
+    if n:
+        mfma[name] = {"launches": n, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui, "SQ_WAVE_CYCLES": waves,
+                      "SQ_BUSY_CYCLES": sqb, "SQ_INSTS_VALU_MFMA_MOPS_F32": mops,
+                      # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA_BUSY over all 1024 SIMDs' pipes
+                      "mfma_busy_frac": busy / (gui / 8.0 * 1024.0) if gui else None}
+summary["gemm_mfma"] = mfma
+if gemm_fetch and gemm_write:
+    rd = 2 * 1024 * sum(gemm_fetch) / len(gemm_fetch)
+    wr = 1024 * sum(gemm_write) / len(gemm_write)
+    summary["cfg2"] = {"gemm_launches": len(gemm_fetch), "gemm_read_bytes_per_launch": rd,
+                       "gemm_write_bytes_per_launch": wr, "gemm_hbm_bytes_per_launch": rd + wr,
+                       "correction": "read = 2 x FETCH_SIZE KiB (gfx950 16-B/lane streams), write = WRITE_SIZE KiB"}
+json.dump(summary, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
+if "cfg2" in summary:
+    json.dump({"cfg2": summary["cfg2"], "source": f"profiles/{tag}_pmc_summary.json"},
+              open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
+
+with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
+    f.write(f"# rocprofv3 summary, round {tag} (cfg2: B=32, N=4096, V=64, fp32)\n\n")
+    f.write("## kernel-trace --stats (3 timed + 1 warm-up steps)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for n, c, t, a, pc in stats_rows[:30]:
+        f.write(f"| `{n}` | {c} | {t:.2f} | {a:.1f} | {pc:.1f} |\n")
+    if "cfg2" in summary:
+        c = summary["cfg2"]
+        f.write(f"\n## HBM traffic of the dominant kernel (128x128 fp32-MFMA GEMM, launches >= {BIG_US:.0f} us)\n\n")
+        f.write(f"launches {c['gemm_launches']}: read {c['gemm_read_bytes_per_launch'] / 1e6:.1f} MB + write "
+                f"{c['gemm_write_bytes_per_launch'] / 1e6:.1f} MB = {c['gemm_hbm_bytes_per_launch'] / 1e6:.1f} MB per launch "
+                f"({c['correction']})\n")
+    if mfma:
+        f.write("\n## MFMA pipe occupancy of the dominant kernel (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))\n\n")
+        for n, e in mfma.items():
+            f.write(f"* `{n}`: {e['launches']} launches, busy fraction {e['mfma_busy_frac']:.3f}\n")
+print(open(os.path.join(P, f"{tag}_summary.md")).read())
