@@ -26,6 +26,9 @@ for K, N in layers:
     cases.append((f"NT+pro K={K} N={N}", lambda X=X, W=W, pro=pro, o=o_nt: ops.gemm(X, W, ops.NT, pro=pro, out=o), fl))
     cases.append((f"NT     K={K} N={N}", lambda X=X, W=W, o=o_nt: ops.gemm(X, W, ops.NT, out=o), fl))
     cases.append((f"NN     K={N} N={K}", lambda G=G, W=W, o=o_nn: ops.gemm(G, W, ops.NN, out=o), fl))
+    Xs, Ws, Gs, WTs = ops.split_rows(X), ops.split_rows(W), ops.split_rows(G), ops.split_rows(W, transpose=True)
+    cases.append((f"SPLIT NT K={K} N={N}", lambda Xs=Xs, Ws=Ws, o=o_nt: ops.gemm_split(Xs, Ws, out=o), fl))
+    cases.append((f"SPLIT dgrad K={N} N={K}", lambda Gs=Gs, WTs=WTs, o=o_nn: ops.gemm_split(Gs, WTs, out=o), fl))
     cases.append((f"TN+pro K={M} out={N}x{K}", lambda G=G, X=X, pro=pro, o=o_tn: ops.gemm(G, X, ops.TN, pro=pro, out=o), fl))
 times = {c[0]: [] for c in cases}
 for c in cases:
@@ -42,7 +45,7 @@ for r in range(5):
 tot = 0.0
 for name, fn, fl in cases:
     ms = statistics.median(times[name])
-    if not name.startswith("NT  "):
+    if not name.startswith("NT  ") and not name.startswith("SPLIT"):
         tot += ms
     print(f"{name:34s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
 print(f"sum (NT+pro, NN, TN+pro) = {tot:.2f} ms")

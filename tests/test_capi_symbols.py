@@ -40,7 +40,7 @@ def test_argument_errors_reported_without_gpu():
     d.K = 4                                  # null operands
     assert lib.wf3d_gemm(ctypes.byref(d), None) == -1
     assert lib.wf3d_row_stats(None, 4, 0, 0, 1e-5, None, None, None) == -1
-    assert lib.wf3d_ln_act_bwd(None, None, 4, 6, None, None, None, None, 0, 0.0, 0, None, None, None, None, None, 0, None) == -4
+    assert lib.wf3d_ln_act_bwd(None, None, 4, 6, None, None, None, None, 0, 0.0, 0, None, None, None, None, None, None, 0, None) == -4
     assert lib.wf3d_gemm_ws_bytes(32, 256, 4096, 0) > 0
     assert lib.wf3d_gemm_ws_bytes(4096, 4096, 64, 0) == 0
 

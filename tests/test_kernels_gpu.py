@@ -248,3 +248,104 @@ def test_bad_arguments_raise(ops):
         ops.gemm(rnd(4, 5), rnd(4, 6), ops.NT)
     with pytest.raises(RuntimeError):
         ops.ln_act_bwd(rnd(4, 6), rnd(4, 6), None, None, None, None, 0)    # D % 4 != 0
+
+
+# ---------------------------------------------------------------------------
+# bf16x3 split-precision path (sx8 operands)
+# ---------------------------------------------------------------------------
+def unpack_sx8(t):
+    """sx8 tensor [R, C] (fp32 container) -> (hi, lo) float32 [R, C]."""
+    R, C = t.shape
+    b = t.contiguous().view(torch.bfloat16).reshape(R, C // 8, 2, 8)
+    return b[:, :, 0, :].reshape(R, C).float(), b[:, :, 1, :].reshape(R, C).float()
+
+
+def ref_split(x):
+    hi = x.to(torch.bfloat16).float()
+    lo = (x - hi).to(torch.bfloat16).float()
+    return hi, lo
+
+
+TOL_SPLIT = 3e-5      # bf16x3 keeps ~16 significant bits per product; gate on the path is 1e-4
+
+
+@pytest.mark.parametrize("R,C", [(5, 8), (300, 512), (64, 1032)])
+def test_split_rows_format_and_transpose(ops, R, C):
+    X = rnd(R, C, seed=1, scale=3.0)
+    hi, lo = unpack_sx8(ops.split_rows(X))
+    rh, rl = ref_split(X)
+    assert torch.equal(hi, rh) and torch.equal(lo, rl)                  # bit-exact RNE split
+    assert rel(hi + lo, X) < 2 ** -15
+    if R % 8 == 0:
+        th, tl = unpack_sx8(ops.split_rows(X, transpose=True))
+        assert torch.equal(th, rh.T) and torch.equal(tl, rl.T)
+    V = X[:, : (C // 16) * 8] if C >= 16 else X                          # strided view input
+    vh, _ = unpack_sx8(ops.split_rows(V))
+    assert torch.equal(vh, ref_split(V.contiguous())[0])
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 104), (1000, 512, 512), (64, 96, 2048), (4096, 1024, 1024)])
+def test_gemm_split_matches_fp64(ops, M, N, K):
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    got = ops.gemm_split(ops.split_rows(A), ops.split_rows(B), bias=bias)
+    want = ref64(lambda a, b, c: a @ b.T + c, A, B, bias)
+    assert rel(got, want) < TOL_SPLIT
+    C0 = rnd(M, N, seed=4)
+    out = C0.clone()
+    ops.gemm_split(ops.split_rows(A), ops.split_rows(B), out=out, accumulate=True)
+    assert rel(out, want - bias.double().cpu() + C0.double().cpu()) < TOL_SPLIT
+    # dgrad form: dX = dY · W  ==  gemm_split(dY_s, (W^T)_s)
+    G = rnd(M, N, seed=5)
+    got = ops.gemm_split(ops.split_rows(G), ops.split_rows(B, transpose=True)) if N % 8 == 0 else None
+    if got is not None:
+        assert rel(got, ref64(lambda g, w: g @ w, G, B)) < TOL_SPLIT
+
+
+def test_gemm_split_long_k_splitk(ops):
+    M, N, K = 96, 200, 65536           # wgrad-like: few tiles, long reduction -> split-K slabs
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    assert ops._lib.load().wf3d_gemm_split_ws_bytes(M, N, K) > 0
+    got = ops.gemm_split(ops.split_rows(A), ops.split_rows(B))
+    assert rel(got, ref64(lambda a, b: a @ b.T, A, B)) < TOL_SPLIT
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("R,D", [(37, 32), (300, 512), (129, 2048), (5, 4096)])
+def test_ln_prep_and_bwd_split_output(ops, act, R, D):
+    Z = rnd(R, D, seed=1, scale=1.5) + 0.2
+    gamma, beta = 1 + 0.2 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    mu, rs, hs = ops.ln_prep(Z, gamma, beta, act)
+    mu2, rs2 = ops.row_stats(Z)
+    assert rel(mu, mu2) < 1e-6 and rel(rs, rs2) < 1e-6
+    hi, lo = unpack_sx8(hs)
+    want = ref64(lambda z, g, b: ln_ref(z, g, b, act), Z, gamma, beta)
+    assert rel(hi + lo, want) < 2e-5
+    h32 = ops.ln_act_apply(Z, mu, rs, gamma, beta, act)
+    rh, rl = ref_split(h32)
+    assert (hi - rh).abs().max() <= 2 ** -7 * h32.abs().max()           # same split up to 1-ulp LN differences
+    dh = rnd(R, D, seed=4)
+    ds = torch.empty_like(Z)
+    dz, _, _, _ = ops.ln_act_bwd(dh, Z, mu, rs, gamma, beta, act, dz_split=ds)
+    dh_, dl_ = unpack_sx8(ds)
+    eh, el = ref_split(dz)
+    assert torch.equal(dh_, eh) and torch.equal(dl_, el)                 # sx8 copy of dz is the exact split of dz
+
+
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("R,C", [(64, 64), (200, 36), (1000, 512), (72, 1028)])
+def test_split_transpose_and_wgrad_form(ops, act, R, C):
+    Z = rnd(R, C, seed=1, scale=1.5) + 0.1
+    th, tl = unpack_sx8(ops.split_transpose(Z))
+    rh, rl = ref_split(Z)
+    assert torch.equal(th, rh.T) and torch.equal(tl, rl.T)
+    gamma, beta = 1 + 0.2 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    mu, rs = ops.row_stats(Z)
+    pro = ops.Pro(act, mu, rs, gamma, beta)
+    ph, pl = unpack_sx8(ops.split_transpose(Z, pro))
+    want = ref64(lambda z, g, b: ln_ref(z, g, b, act), Z, gamma, beta)
+    assert rel((ph + pl).T, want) < 2e-5
+    # wgrad: dW[N, C] = G^T · act(LN(Z))  via NT-form split GEMM on the transposed operands
+    N = 96
+    G = rnd(R, N, seed=5)
+    dW = ops.gemm_split(ops.split_transpose(G), ops.split_transpose(Z, pro))
+    assert rel(dW, G.double().cpu().T @ want) < TOL_SPLIT

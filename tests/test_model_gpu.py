@@ -28,7 +28,19 @@ def load_arrays(module, arrs, prefix=""):
             v.copy_(torch.from_numpy(arrs[prefix + k]))
 
 
-def test_small_encoder_vs_golden():
+@pytest.fixture(params=["fp32", "bf16x3"])
+def precision(request):
+    """Run a test in both arithmetic modes; bf16x3 is forced onto small shapes too."""
+    from wf3d import config
+    old = (config.precision(), config.SPLIT_MIN_ROWS)
+    config.set_precision(request.param)
+    config.SPLIT_MIN_ROWS = 1
+    yield request.param
+    config.set_precision(old[0])
+    config.SPLIT_MIN_ROWS = old[1]
+
+
+def test_small_encoder_vs_golden(precision):
     from models.PointNetEncoder import PointNetEncoder
     gold = H.load_golden("small_enc")
     shapes = H.sub_shapes("encoder.", input_dim=8, hidden_dims=(32, 64), output_dim=16)
@@ -123,7 +135,7 @@ def build_full(tag):
 
 
 @pytest.mark.parametrize("tag", ["cfg1", "ragged", "evalmode"])
-def test_full_model_vs_golden_and_oracle(tag):
+def test_full_model_vs_golden_and_oracle(tag, precision):
     gold, model, x, arrs, counts, V, seed, train = build_full(tag)
     xd = torch.from_numpy(x).to(dev())
     cd = counts.to(dev()) if counts is not None else None
@@ -244,3 +256,34 @@ def test_attention_vs_torch_mha():
     assert H.rel_err(ctx.cpu().numpy(), ref.detach().numpy()) < 2e-5
     (ref * dctx.double().cpu()).sum().backward()
     assert H.rel_err(dqkv.cpu().numpy(), q64.grad.numpy()) < 1e-4
+
+
+def test_split_mode_is_active_and_close_to_fp32():
+    """At cfg1 size the default mode must take the split-GEMM path (kernel really used) and
+    agree with the fp32 mode to ~1e-5 on outputs."""
+    from wf3d import config, ops
+    gold, model, x, arrs, counts, V, seed, train = build_full("cfg1")
+    xd, cd = torch.from_numpy(x).to(dev()), counts.to(dev())
+    calls = {"n": 0}
+    orig = ops.gemm_split
+
+    def spy(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    ops.gemm_split = spy
+    try:
+        assert config.precision() == "bf16x3"
+        out_s = model(xd, cd)
+        sum(out_s[k].sum() for k in ("vertices", "edge_probs")).backward()
+    finally:
+        ops.gemm_split = orig
+    assert calls["n"] == 4 + 4 + 4          # 4 forward, 4 dgrad, 4 wgrad split GEMMs (layers 2..5)
+    config.set_precision("fp32")
+    try:
+        out_f = model(xd, cd)
+    finally:
+        config.set_precision("bf16x3")
+    for k in ("vertices", "existence_probabilities", "edge_probs", "global_features"):
+        e = H.rel_err(out_s[k].detach().cpu().numpy(), out_f[k].detach().cpu().numpy())
+        assert e < 5e-5, (k, e)

@@ -29,6 +29,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct GemmParams {
     const float* A; const float* B; float* C;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void load_tile_fast(const float* __restrict__ p0, int
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool FAST>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool FAST, bool SPLIT>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int m0, int n0, int kt0, int kt1) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
@@ -266,6 +267,34 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
         if (more) fetch(kt + 1);                       // global loads in flight under the MFMAs
         const float* As = smem + stage * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
+        if (SPLIT) {
+            // bf16x3 split precision: each 32-B group of a staged row holds [8 x hi | 8 x lo] bf16 of 8
+            // consecutive k; a*b ~= ah*bh + ah*bl + al*bh (fp32 accumulate), v_mfma_f32_32x32x16_bf16.
+#pragma unroll
+            for (int s2 = 0; s2 < BK / 16; ++s2) {
+                f32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float* pr = As + ((wm * TM + i) * 32 + l31) * LDK + (2 * s2 + h) * 8;
+                    ah[i] = *reinterpret_cast<const f32x4*>(pr);
+                    al[i] = *reinterpret_cast<const f32x4*>(pr + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* pr = Bs + ((wn * TN + j) * 32 + l31) * LDK + (2 * s2 + h) * 8;
+                    bh[j] = *reinterpret_cast<const f32x4*>(pr);
+                    bl[j] = *reinterpret_cast<const f32x4*>(pr + 4);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
             f32x4 fa[TM], fb[TN];
@@ -280,6 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
         }
         if (more) commit(kt + 1, stage ^ 1);
         __syncthreads();
@@ -314,7 +344,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
@@ -338,8 +368,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // FAST: every staged tile of this workgroup lies fully inside A and B and is
     // 16-B loadable -> branch-free staging (block-uniform choice)
     const bool fast = p.vecA && p.vecB && p.vecP && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (kt1 * BK <= p.K);
-    if (fast) gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, true>(p, smem, m0, n0, kt0, kt1);
-    else      gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, false>(p, smem, m0, n0, kt0, kt1);
+    if (fast) gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, true, SPLIT>(p, smem, m0, n0, kt0, kt1);
+    else      gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, false, SPLIT>(p, smem, m0, n0, kt0, kt1);
 }
 
 // split-K combine: deterministic slab sum + epilogue terms
@@ -460,6 +490,52 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const size_t total = (size_t)p.M * p.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        WF3D_LAUNCH_CHECK();
+    }
+    return WF3D_OK;
+}
+
+// ---------------------------------------------------------------------------
+// bf16x3 split-precision GEMM (NT form): C[M,N] = A·B^T (+bias) with A, B in the
+// "sx8" split format produced by wf3d_split_rows / wf3d_ln_prep: logical [R, K]
+// fp32 values stored as [R][K/8][2][8] bf16 = 8 high parts then 8 low parts per
+// 8 consecutive k (same bytes and row pitch as the fp32 tensor).
+// ---------------------------------------------------------------------------
+extern "C" size_t wf3d_gemm_split_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    SplitPlan s = plan_split(M, N, K, 128, 128);
+    return s.ksplit > 1 ? (size_t)s.ksplit * M * N * sizeof(float) : 0;
+}
+
+extern "C" int wf3d_gemm_split(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N, int K,
+                               int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    WF3D_CHECK(M >= 0 && N >= 0 && K > 0, WF3D_ERR_ARG, "wf3d_gemm_split: bad dims");
+    if (M == 0 || N == 0) return WF3D_OK;
+    WF3D_CHECK(A_sx8 && B_sx8 && C, WF3D_ERR_ARG, "wf3d_gemm_split: null operand");
+    WF3D_CHECK(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, WF3D_ERR_UNSUPPORTED,
+               "wf3d_gemm_split: K, lda, ldb must be multiples of 8 (sx8 groups)");
+    WF3D_CHECK(lda >= K && ldb >= K && ldc >= N, WF3D_ERR_ARG, "wf3d_gemm_split: leading dimension too small");
+    WF3D_CHECK(((uintptr_t)A_sx8 % 16 == 0) && ((uintptr_t)B_sx8 % 16 == 0), WF3D_ERR_ARG, "wf3d_gemm_split: operands must be 16-byte aligned");
+    GemmParams p{};
+    p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.accumulate = accumulate;
+    p.vecA = p.vecB = p.vecP = 1;
+    p.nbm = wf3d_cdiv(M, 128); p.nbn = wf3d_cdiv(N, 128);
+    SplitPlan sp = plan_split(M, N, K, 128, 128);
+    const size_t need = sp.ksplit > 1 ? (size_t)sp.ksplit * M * N * sizeof(float) : 0;
+    if (need && (ws == nullptr || ws_bytes < need)) { sp.ksplit = 1; sp.kt_per = wf3d_cdiv(K, BK); }
+    p.ksplit = sp.ksplit; p.kt_per_split = sp.kt_per;
+    p.slab = sp.ksplit > 1 ? (float*)ws : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(p.nbm * p.nbn, 1, p.ksplit);
+    hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, true, true, 0, false, true>), grid, dim3(256), 0, st, p);
+    WF3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const size_t total = (size_t)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);

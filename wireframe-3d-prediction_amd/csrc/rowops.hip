@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
                                                           const float* __restrict__ rs, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, uint32_t seed,
                                                           uint32_t thresh, float scale, float* __restrict__ dz,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ dz_sx8, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [3][D] block combine
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool has_ln = mu != nullptr;
@@ -137,6 +137,23 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
                     a_dg[i][j] += g * x; a_db[i][j] += g; a_dbias[i][j] += o[j];
                 }
                 *reinterpret_cast<f32x4*>(dz + (size_t)row * D + c) = o;
+                if (dz_sx8) {
+                    // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts,
+                    // odd lane the 8 low parts, after swapping the halves they do not own
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)o[j]; lo[j] = (__bf16)(o[j] - (float)hi[j]); }
+                    const uint2 mine_hi = __builtin_bit_cast(uint2, hi), mine_lo = __builtin_bit_cast(uint2, lo);
+                    const bool odd = lane & 1;
+                    uint2 send = odd ? mine_hi : mine_lo, got;
+                    got.x = __shfl_xor((int)send.x, 1, 64);
+                    got.y = __shfl_xor((int)send.y, 1, 64);
+                    uint4 w = odd ? make_uint4(got.x, got.y, mine_lo.x, mine_lo.y)
+                                  : make_uint4(mine_hi.x, mine_hi.y, got.x, got.y);
+                    float* g = dz_sx8 + (size_t)row * D + (c & ~7) + (odd ? 4 : 0);
+                    *reinterpret_cast<uint4*>(g) = w;
+                }
             }
         }
     }
@@ -161,21 +178,25 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     for (int idx = threadIdx.x; idx < 3 * D; idx += 256) part[(size_t)blockIdx.x * 3 * D + idx] = red[idx];
 }
 
-// out[c] = sum_b part[b*stride + c]
+// out[c] = sum_b part[b*stride + c].  64 columns per workgroup, the partial rows
+// split 4 ways over the waves (coalesced 256-B reads), combined through LDS.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, size_t stride,
                                                                int D, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += part[(size_t)b * stride + c];
-        s1 += part[(size_t)(b + 1) * stride + c];
-        s2 += part[(size_t)(b + 2) * stride + c];
-        s3 += part[(size_t)(b + 3) * stride + c];
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < D) {
+        int b = sub;
+        for (; b + 4 < nblk; b += 8) {
+            s0 += part[(size_t)b * stride + c];
+            s1 += part[(size_t)(b + 4) * stride + c];
+        }
+        for (; b < nblk; b += 4) s0 += part[(size_t)b * stride + c];
     }
-    for (; b < nblk; ++b) s0 += part[(size_t)b * stride + c];
-    out[c] = (s0 + s1) + (s2 + s3);
+    red[sub][lane] = s0 + s1;
+    __syncthreads();
+    if (sub == 0 && c < D) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // partial column sums: block (bx, by) sums rows [by*rpb, ...) of columns bx*256..
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 int bwd_nblk(int R) {
     int n = wf3d_cdiv(R, 4);
-    return n > 1024 ? 1024 : (n < 1 ? 1 : n);
+    return n > 512 ? 512 : (n < 1 ? 1 : n);
 }
 int colsum_nrb(int R) {
     int n = wf3d_cdiv(R, 64);
@@ -237,9 +258,11 @@ extern "C" size_t wf3d_ln_act_bwd_ws_bytes(int R, int D) {
 
 extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, const float* mu, const float* rs,
                                const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
-                               float* dz, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                               void* stream) {
+                               float* dz, void* dz_sx8, float* dgamma, float* dbeta, float* dbias, void* ws,
+                               size_t ws_bytes, void* stream) {
     WF3D_CHECK(R >= 0 && D > 0, WF3D_ERR_ARG, "wf3d_ln_act_bwd: bad dims");
+    WF3D_CHECK(!dz_sx8 || (D % 8 == 0 && (uintptr_t)dz_sx8 % 16 == 0), WF3D_ERR_UNSUPPORTED,
+               "wf3d_ln_act_bwd: the sx8 output needs D %% 8 == 0 and 16-byte alignment");
     WF3D_CHECK(D % 4 == 0 && D <= 4096, WF3D_ERR_UNSUPPORTED, "wf3d_ln_act_bwd: D=%d must be a multiple of 4, <= 4096", D);
     WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_ln_act_bwd: bad act/drop");
     WF3D_CHECK(!mu || rs, WF3D_ERR_ARG, "wf3d_ln_act_bwd: mu without rs");
@@ -264,7 +287,7 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
     const int ns = wf3d_cdiv(D, 256);
 #define WF3D_BWD(NS_)                                                                                              \
     hipLaunchKernelGGL((ln_act_bwd_kernel<NS_>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
-                       act, drop_seed, thresh, scale, dz, part)
+                       act, drop_seed, thresh, scale, dz, (float*)dz_sx8, part)
     if (ns <= 1) WF3D_BWD(1);
     else if (ns <= 2) WF3D_BWD(2);
     else if (ns <= 4) WF3D_BWD(4);
@@ -273,9 +296,16 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
 #undef WF3D_BWD
     WF3D_LAUNCH_CHECK();
     float* outs[3] = {dgamma, dbeta, dbias};
+    if (dgamma && dbeta == dgamma + D && dbias == dbeta + D) {
+        // the three outputs are one contiguous [3][D] buffer: a single finalize pass
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 64)), dim3(256), 0, st, part, nblk,
+                           (size_t)3 * D, 3 * D, dgamma);
+        WF3D_LAUNCH_CHECK();
+        return WF3D_OK;
+    }
     for (int k = 0; k < 3; ++k) {
         if (!outs[k]) continue;
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 256)), dim3(256), 0, st, part + (size_t)k * D, nblk,
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 64)), dim3(256), 0, st, part + (size_t)k * D, nblk,
                            (size_t)3 * D, D, outs[k]);
         WF3D_LAUNCH_CHECK();
     }
@@ -299,7 +329,7 @@ extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w,
     float* part = (float*)ws;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(wf3d_cdiv(D, 256), nrb), dim3(256), 0, st, x, R, D, ld, w, rpb, part);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 256)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 64)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
                        (size_t)D, D, out);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;

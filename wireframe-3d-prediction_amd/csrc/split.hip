@@ -1,0 +1,202 @@
+// Producers of the "sx8" split-precision operand format consumed by wf3d_gemm_split.
+//
+// sx8: a logical fp32 matrix [R, C] (C % 8 == 0) stored with the SAME bytes and row
+// pitch as fp32, but every 32-byte group of 8 consecutive columns holds
+//     [ 8 x bf16 high parts | 8 x bf16 low parts ],   v ~= hi + lo,
+// hi = bf16_rne(v), lo = bf16_rne(v - hi)  (|v - hi - lo| <= 2^-17 |v|).  A staged
+// row slice then delivers each lane's v_mfma_f32_32x32x16_bf16 fragment (8
+// consecutive k) as one 16-byte chunk, with no conversion inside the GEMM.
+#include "wf3d_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void store_sx8(float* dst, const float (&v)[8]) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+    *reinterpret_cast<f32x4*>(dst) = __builtin_bit_cast(f32x4, hi);
+    *reinterpret_cast<f32x4*>(dst + 4) = __builtin_bit_cast(f32x4, lo);
+}
+
+// out_sx8[r, c] = in[r*rs + c*cs]   (cs == 1: plain copy-convert; rs == 1: transpose)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, long rs, long cs, int R, int C,
+                                                          float* __restrict__ out) {
+    const long groups = (long)R * (C / 8);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < groups; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / (C / 8)), g = (int)(idx % (C / 8));
+        const float* p = in + (long)r * rs + (long)g * 8 * cs;
+        float v[8];
+        if (cs == 1 && (((uintptr_t)p) % 16 == 0)) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(long)j * cs];
+        }
+        store_sx8(out + (long)r * C + (long)g * 8, v);
+    }
+}
+
+// LayerNorm statistics + h = act(LN(z)) written in sx8: one wave per row, the row
+// lives in registers (NS slots of 8 columns per lane), z is read from HBM once.
+template <int NS>
+__global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ z, int R, int D,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int act, float eps, float* __restrict__ mu, float* __restrict__ rs,
+                                                       float* __restrict__ h_sx8) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* p = z + (size_t)row * D;
+    float v[NS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane * 8 + 512 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        if (c < D) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[i][j] = a[j]; v[i][4 + j] = b[j]; s += a[j] + b[j]; }
+        }
+    }
+    const float mean = wf3d_wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane * 8 + 512 * i;
+        if (c < D)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wf3d_wave_sum(q) / (float)D + eps);
+    if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane * 8 + 512 * i;
+        if (c < D) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * g0[j] + b0[j]);
+                o[4 + j] = wf3d_act_rt(act, (v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+            }
+            store_sx8(h_sx8 + (size_t)row * D + c, o);
+        }
+    }
+}
+
+
+// out_sx8[c, r] = split( pro(in[r, c]) ): tiled transpose through LDS so that both the
+// fp32 reads (256 B per 16 lanes) and the sx8 writes (128 B per 4 lanes) are coalesced.
+// pro = optional act(LN-affine(.)) with per-row (mu, rs) and per-column (gamma, beta):
+// this is how the wgrad operands h^T and dz^T (k = point index contiguous) are produced.
+__global__ __launch_bounds__(256) void split_transpose_kernel(const float* __restrict__ in, int R, int C, int ld,
+                                                               const float* __restrict__ mu, const float* __restrict__ rs,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act,
+                                                               float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    {
+        const int cc = (t & 15) * 4;
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma && c0 + cc < C) { g = *reinterpret_cast<const f32x4*>(gamma + c0 + cc); b = *reinterpret_cast<const f32x4*>(beta + c0 + cc); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = (t >> 4) + 16 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r0 + rr < R && c0 + cc < C) {
+                v = *reinterpret_cast<const f32x4*>(in + (size_t)(r0 + rr) * ld + c0 + cc);
+                if (mu) {
+                    const float m = mu[r0 + rr], s = rs[r0 + rr];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (v[j] - m) * s;
+                }
+                if (gamma) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * g[j] + b[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = wf3d_act_rt(act, v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[rr][cc + j] = v[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = t >> 2, g8 = (t & 3) + 4 * j;          // output row c0+c, group of 8 source rows
+        if (c0 + c < C && r0 + g8 * 8 < R) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tile[g8 * 8 + k][c];
+            store_sx8(out + (size_t)(c0 + c) * R + r0 + g8 * 8, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int wf3d_split_rows(const float* in, long row_stride, long col_stride, int R, int C, void* out_sx8,
+                               void* stream) {
+    WF3D_CHECK(R >= 0 && C > 0 && C % 8 == 0, WF3D_ERR_UNSUPPORTED, "wf3d_split_rows: C=%d must be a positive multiple of 8", C);
+    if (R == 0) return WF3D_OK;
+    WF3D_CHECK(in && out_sx8 && ((uintptr_t)out_sx8 % 16 == 0), WF3D_ERR_ARG, "wf3d_split_rows: null or misaligned pointer");
+    const long groups = (long)R * (C / 8);
+    long blocks = (groups + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, row_stride,
+                       col_stride, R, C, (float*)out_sx8);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, const float* beta, int act, float eps,
+                            float* mu, float* rs, void* h_sx8, void* stream) {
+    WF3D_CHECK(R >= 0 && D > 0, WF3D_ERR_ARG, "wf3d_ln_prep: bad dims");
+    WF3D_CHECK(D % 8 == 0 && D <= 4096, WF3D_ERR_UNSUPPORTED, "wf3d_ln_prep: D=%d must be a multiple of 8, <= 4096", D);
+    WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_ln_prep: bad act");
+    if (R == 0) return WF3D_OK;
+    WF3D_CHECK(z && gamma && beta && mu && rs && h_sx8, WF3D_ERR_ARG, "wf3d_ln_prep: null pointer");
+    WF3D_CHECK(((uintptr_t)z % 16 == 0) && ((uintptr_t)h_sx8 % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+               ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_ln_prep: pointers must be 16-byte aligned");
+    const int ns = wf3d_cdiv(D, 512);
+    hipStream_t st = (hipStream_t)stream;
+#define WF3D_LP(NS_)                                                                                              \
+    hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(wf3d_cdiv(R, 4)), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
+                       mu, rs, (float*)h_sx8)
+    if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
+#undef WF3D_LP
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_split_transpose(const float* in, int R, int C, int ld, const float* mu, const float* rs,
+                                    const float* gamma, const float* beta, int act, void* out_sx8, void* stream) {
+    WF3D_CHECK(R > 0 && C > 0 && ld >= C, WF3D_ERR_ARG, "wf3d_split_transpose: bad dims");
+    WF3D_CHECK(R % 8 == 0 && C % 4 == 0 && ld % 4 == 0, WF3D_ERR_UNSUPPORTED,
+               "wf3d_split_transpose: R %% 8, C %% 4 and ld %% 4 must be 0 (R=%d C=%d ld=%d)", R, C, ld);
+    WF3D_CHECK(in && out_sx8 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out_sx8 % 16 == 0), WF3D_ERR_ARG,
+               "wf3d_split_transpose: null or misaligned pointer");
+    WF3D_CHECK(!mu || rs, WF3D_ERR_ARG, "wf3d_split_transpose: mu without rs");
+    WF3D_CHECK(!gamma || (beta && (uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0), WF3D_ERR_ARG,
+               "wf3d_split_transpose: gamma/beta must both be given, 16-byte aligned");
+    WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_split_transpose: bad act");
+    WF3D_CHECK(wf3d_cdiv(R, 64) <= 65535, WF3D_ERR_UNSUPPORTED, "wf3d_split_transpose: too many rows");
+    hipLaunchKernelGGL(split_transpose_kernel, dim3(wf3d_cdiv(C, 64), wf3d_cdiv(R, 64)), dim3(256), 0,
+                       (hipStream_t)stream, in, R, C, ld, mu, rs, gamma, beta, act, (float*)out_sx8);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}

@@ -7,6 +7,7 @@ are parameter containers only: forward never calls them, it hands their tensors
 to wf3d.functional.EncoderFn (HIP kernels through the C ABI)."""
 import torch.nn as nn
 
+from wf3d import config
 from wf3d.functional import EncoderFn
 
 
@@ -32,6 +33,7 @@ class PointNetEncoder(nn.Module):
             nn.Linear(4 * d, 2 * d), nn.LayerNorm(2 * d), nn.ReLU(inplace=True),
             nn.Linear(2 * d, d))
         self._n_hidden = len(hidden_dims)
+        self.precision = None          # None -> wf3d.config.precision() ("bf16x3" | "fp32")
 
     def _param_list(self):
         ps = []
@@ -51,7 +53,7 @@ class PointNetEncoder(nn.Module):
         pools are what VertexPredictor would recompute from point_features."""
         if x.dim() != 3:
             raise ValueError(f"expected (batch, num_points, input_dim), got {tuple(x.shape)}")
-        return EncoderFn.apply(x.float(), self._n_hidden, *self._param_list())
+        return EncoderFn.apply(x.float(), self._n_hidden, self.precision or config.precision(), *self._param_list())
 
     def forward(self, x):
         g, pf, _, _ = self.encode(x)

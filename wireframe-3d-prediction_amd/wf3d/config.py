@@ -1,0 +1,27 @@
+"""Run-time configuration of the HIP path.
+
+precision
+    "bf16x3" (default): the large per-point Linear layers (rows >= SPLIT_MIN_ROWS) run as
+             split-precision GEMMs — fp32 operands split into bf16 high + low parts, three
+             bf16 MFMAs per product, fp32 accumulation: results agree with the fp32 path to
+             ~1e-5 (inside the 1e-4 parity gate) at ~3x the fp32-MFMA throughput.
+    "fp32":  every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+Environment override: WF3D_PRECISION.
+"""
+import os
+
+SPLIT_MIN_ROWS = 1024
+_precision = os.environ.get("WF3D_PRECISION", "bf16x3")
+if _precision not in ("fp32", "bf16x3"):
+    raise RuntimeError(f"WF3D_PRECISION={_precision!r}: expected 'fp32' or 'bf16x3'")
+
+
+def precision():
+    return _precision
+
+
+def set_precision(p):
+    global _precision
+    if p not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    _precision = p

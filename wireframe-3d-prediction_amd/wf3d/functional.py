@@ -14,7 +14,7 @@ normalised activations never exist in memory.
 """
 import torch
 
-from . import ops
+from . import config, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, NN, NT, TN, Pro
 
 
@@ -30,33 +30,58 @@ def _lin_bwd(dz, a, W, pro_a, need_da=True):
 # ===========================================================================
 # Encoder
 # ===========================================================================
+def _split_ok(rows, k, split):
+    """A Linear runs as a bf16x3 split GEMM when the mode asks for it, the layer is big
+    enough to be MFMA-bound and its reduction width fits the 8-column sx8 groups."""
+    return split and rows >= config.SPLIT_MIN_ROWS and k % 8 == 0 and k >= 32
+
+
 class EncoderFn(torch.autograd.Function):
     """x[B,N,Din], params -> (global[B,C], point_features[B,N,C], umean[B,C], umax[B,C]).
 
     params = [W_i, b_i, gamma_i, beta_i]*n_hidden + [W_out, b_out]
              + [F0w, F0b, F1g, F1b, F3w, F3b, F4g, F4b, F6w, F6b]
     umean/umax are the UNMASKED pools the vertex head needs
-    (VertexPredictor.py:86-87), produced by the same pass as the masked ones."""
+    (VertexPredictor.py:86-87), produced by the same pass as the masked ones.
+
+    precision "bf16x3": layers whose input width is a multiple of 8 consume the previous
+    layer's relu(LN(z)) as an sx8 split operand produced by wf3d_ln_prep (which also
+    yields the LN statistics), through wf3d_gemm_split; backward uses split GEMMs for
+    dgrad (W^T in sx8) and wgrad (transposed sx8 operands).  Only z and (mu, rstd) are
+    kept for backward in either mode."""
 
     @staticmethod
-    def forward(ctx, x, n_hidden, *params):
+    def forward(ctx, x, n_hidden, precision, *params):
         B, N, Din = x.shape
-        x2 = x.reshape(B * N, Din)
+        M = B * N
+        x2 = x.reshape(M, Din)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
+        split = precision == "bf16x3"
         valid = ops.point_valid(x2)
         zs, stats = [], []
-        a, pro = x2, None
-        for i in range(n_hidden):
-            W, b, g, be = params[4 * i:4 * i + 4]
-            z = ops.gemm(a, W, NT, bias=b, pro=pro)
-            mu, rs = ops.row_stats(z)
+        a, a_s, pro = x2, None, None
+        for i in range(n_hidden + 1):
+            last = i == n_hidden
+            W, b = params[4 * i], params[4 * i + 1]
+            if a_s is not None:
+                z = ops.gemm_split(a_s, ops.split_rows(W), bias=b)
+            else:
+                z = ops.gemm(a, W, NT, bias=b, pro=pro)
+            a_s = None
+            if last:
+                pf = z
+                break
+            g, be = params[4 * i + 2], params[4 * i + 3]
+            if _split_ok(M, z.shape[1], split):
+                mu, rs, a_s = ops.ln_prep(z, g, be, ACT_RELU)
+            else:
+                mu, rs = ops.row_stats(z)
             zs.append(z)
             stats.append((mu, rs))
             pro = Pro(ACT_RELU, mu, rs, g, be)
             a = z
-        Wo, bo = params[4 * n_hidden:4 * n_hidden + 2]
-        pf = ops.gemm(a, Wo, NT, bias=bo, pro=pro)                       # [M, C]
+        del a_s
         C = pf.shape[1]
         mmax, mavg, umean, umax, arg_m, arg_u, cnt = ops.pool4_fwd(pf.view(B, N, C), valid)
         pooled = torch.cat([mmax, mavg], dim=1)                           # max first (PointNetEncoder.py:115)
@@ -66,7 +91,7 @@ class EncoderFn(torch.autograd.Function):
         f3 = ops.gemm(f0, F[4], NT, bias=F[5], pro=Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
         s3 = ops.row_stats(f3)
         gl = ops.gemm(f3, F[8], NT, bias=F[9], pro=Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
-        ctx.n_hidden, ctx.dims = n_hidden, (B, N, C)
+        ctx.n_hidden, ctx.dims, ctx.split = n_hidden, (B, N, C), split
         ctx.params = params
         ctx.saved = (x2, valid, zs, stats, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt)
         pf3 = pf.view(B, N, C)
@@ -74,7 +99,8 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dgl, dpf, dumean, dumax):
-        nh, (B, N, C) = ctx.n_hidden, ctx.dims
+        nh, (B, N, C), split = ctx.n_hidden, ctx.dims, ctx.split
+        M = B * N
         params = ctx.params
         x2, valid, zs, stats, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt = ctx.saved
         F = params[4 * nh + 2:]
@@ -101,27 +127,43 @@ class EncoderFn(torch.autograd.Function):
             dumean = dumean.contiguous()
         if dumax is not None:
             dumax = dumax.contiguous()
-        dp = ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C).view(B * N, C)
-        # per-point MLP backward
-        last = 4 * nh
-        a_prev = zs[nh - 1] if nh else x2
-        pro_prev = Pro(ACT_RELU, stats[nh - 1][0], stats[nh - 1][1], params[4 * (nh - 1) + 2], params[4 * (nh - 1) + 3]) if nh else None
-        grads[last + 1] = ops.colsum(dp)
-        grads[last], dh = _lin_bwd(dp, a_prev, params[last], pro_prev, need_da=nh > 0)
-        del dp
-        for i in range(nh - 1, -1, -1):
-            W, b, g, be = params[4 * i:4 * i + 4]
-            mu, rs = stats[i]
-            dz, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1] = ops.ln_act_bwd(dh, zs[i], mu, rs, g, be, ACT_RELU, inplace=True)
+        dz = ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C).view(M, C)
+        dz_s = None
+        # per-point MLP backward, output layer first.  Entering iteration i: dz = grad wrt the
+        # pre-LN output of Linear i (fp32) and, in split mode, dz_s = the same in sx8.
+        for i in range(nh, -1, -1):
+            W = params[4 * i]
+            if i < nh:
+                g, be = params[4 * i + 2], params[4 * i + 3]
+                mu, rs = stats[i]
+                want_s = i > 0 and _split_ok(M, W.shape[0], split)
+                dz_s = torch.empty_like(dh) if want_s else None
+                dz, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1] = ops.ln_act_bwd(
+                    dh, zs[i], mu, rs, g, be, ACT_RELU, inplace=True, dz_split=dz_s)
+            else:
+                grads[4 * i + 1] = ops.colsum(dz)
+                if nh and _split_ok(M, W.shape[0], split):
+                    dz_s = ops.split_rows(dz)
             if i > 0:
                 pg, pb = params[4 * (i - 1) + 2], params[4 * (i - 1) + 3]
                 a_prev, pro_prev = zs[i - 1], Pro(ACT_RELU, stats[i - 1][0], stats[i - 1][1], pg, pb)
             else:
                 a_prev, pro_prev = x2, None
-            grads[4 * i], dh = _lin_bwd(dz, a_prev, W, pro_prev, need_da=i > 0)
-            del dz
+            K = W.shape[1]
+            if i > 0 and dz_s is not None and _split_ok(M, K, split) and M % 8 == 0:
+                # wgrad dW = dz^T · h_prev as an NT-form split GEMM over the point index
+                grads[4 * i] = ops.gemm_split(ops.split_transpose(dz), ops.split_transpose(a_prev, pro_prev))
+            else:
+                grads[4 * i] = ops.gemm(dz, a_prev, TN, pro=pro_prev)
+            if i > 0:
+                if dz_s is not None:
+                    dh = ops.gemm_split(dz_s, ops.split_rows(W, transpose=True))     # dgrad: dz · W
+                else:
+                    dh = ops.gemm(dz, W, NN)
+            del dz, dz_s
+            dz = dz_s = None
         ctx.saved = None
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 # ===========================================================================

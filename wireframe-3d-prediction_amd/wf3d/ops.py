@@ -144,21 +144,27 @@ def ln_act_apply(z, mu, rs, gamma, beta, act, addend=None, drop_p=0.0, seed=0, o
     return out
 
 
-def ln_act_bwd(dh, z, mu, rs, gamma, beta, act, drop_p=0.0, seed=0, want_affine=True, want_bias=True, inplace=False):
-    """Returns (dz, dgamma, dbeta, dbias)."""
+def ln_act_bwd(dh, z, mu, rs, gamma, beta, act, drop_p=0.0, seed=0, want_affine=True, want_bias=True, inplace=False,
+               dz_split=None):
+    """Returns (dz, dgamma, dbeta, dbias); `dz_split` (optional sx8 buffer) also receives dz."""
     _need_cuda(dh, z, mu, rs, gamma, beta)
     if not (dh.is_contiguous() and z.is_contiguous()):
         raise RuntimeError("wf3d.ln_act_bwd: contiguous tensors required")
     R, D = z.shape
     dz = dh if inplace else torch.empty_like(z)
     dev = z.device
-    dgamma = torch.empty(D, dtype=torch.float32, device=dev) if (want_affine and gamma is not None) else None
-    dbeta = torch.empty(D, dtype=torch.float32, device=dev) if (want_affine and gamma is not None) else None
-    dbias = torch.empty(D, dtype=torch.float32, device=dev) if want_bias else None
+    if want_affine and gamma is not None and want_bias:
+        # one [3, D] buffer -> the C side finalises all three column sums in a single pass
+        trio = torch.empty(3, D, dtype=torch.float32, device=dev)
+        dgamma, dbeta, dbias = trio[0], trio[1], trio[2]
+    else:
+        dgamma = torch.empty(D, dtype=torch.float32, device=dev) if (want_affine and gamma is not None) else None
+        dbeta = torch.empty(D, dtype=torch.float32, device=dev) if (want_affine and gamma is not None) else None
+        dbias = torch.empty(D, dtype=torch.float32, device=dev) if want_bias else None
     lib = _lib.load()
     ws = scratch(lib.wf3d_ln_act_bwd_ws_bytes(R, D), dev)
     check(lib.wf3d_ln_act_bwd(_p(dh), _p(z), R, D, _p(mu), _p(rs), _p(gamma), _p(beta), act, float(drop_p),
-                              int(seed) & 0xFFFFFFFF, _p(dz), _p(dgamma), _p(dbeta), _p(dbias), _p(ws),
+                              int(seed) & 0xFFFFFFFF, _p(dz), _p(dz_split), _p(dgamma), _p(dbeta), _p(dbias), _p(ws),
                               ws.numel() if ws is not None else 0, _stream()), "ln_act_bwd")
     return dz, dgamma, dbeta, dbias
 
@@ -360,3 +366,69 @@ def edge_prob_bwd(probs, dprobs, meta):
     check(_lib.load().wf3d_edge_prob_bwd(_p(probs), _p(dprobs), _p(meta.eoff), _p(meta.esample), meta.Re, meta.max_e,
                                          _p(dlogit), _stream()), "edge_prob_bwd")
     return dlogit
+
+
+# ---------------------------------------------------------------------------
+# bf16x3 split-precision path ("sx8" operands, see include/wf3d.h)
+# ---------------------------------------------------------------------------
+def split_rows(t, transpose=False):
+    """fp32 [R, C] -> sx8 tensor of the same shape (C % 8 == 0); transpose=True gives split(t.T)."""
+    _need_cuda(t)
+    t = _rows2d(t)
+    if transpose:
+        R, C, rs, cs = t.shape[1], t.shape[0], 1, t.stride(0)
+    else:
+        R, C, rs, cs = t.shape[0], t.shape[1], t.stride(0), 1
+    out = torch.empty(R, C, dtype=torch.float32, device=t.device)
+    check(_lib.load().wf3d_split_rows(_p(t), rs, cs, R, C, _p(out), _stream()), "split_rows")
+    return out
+
+
+def ln_prep(z, gamma, beta, act, eps=LN_EPS):
+    """(mu, rs, h_sx8) with h = act(LayerNorm(z)); z contiguous [R, D], D % 8 == 0."""
+    _need_cuda(z, gamma, beta)
+    if not z.is_contiguous():
+        raise RuntimeError("wf3d.ln_prep: contiguous z required")
+    R, D = z.shape
+    mu = torch.empty(R, dtype=torch.float32, device=z.device)
+    rs = torch.empty(R, dtype=torch.float32, device=z.device)
+    h = torch.empty_like(z)
+    check(_lib.load().wf3d_ln_prep(_p(z), R, D, _p(gamma), _p(beta), act, eps, _p(mu), _p(rs), _p(h), _stream()), "ln_prep")
+    return mu, rs, h
+
+
+def gemm_split(a_s, b_s, bias=None, out=None, accumulate=False):
+    """C[M,N] = A·B^T (+bias) with A = sx8[M,K], B = sx8[N,K] (bf16x3: hi*hi + hi*lo + lo*hi, fp32 accumulate)."""
+    _need_cuda(a_s, b_s, bias, out)
+    a_s, b_s = _rows2d(a_s), _rows2d(b_s)
+    M, K = a_s.shape
+    N, K2 = b_s.shape
+    if K != K2:
+        raise RuntimeError("wf3d.gemm_split: reduction dims differ")
+    if out is None:
+        if accumulate:
+            raise RuntimeError("wf3d.gemm_split: accumulate needs `out`")
+        out = torch.empty(M, N, dtype=torch.float32, device=a_s.device)
+    lib = _lib.load()
+    ws = scratch(lib.wf3d_gemm_split_ws_bytes(M, N, K), a_s.device)
+    check(lib.wf3d_gemm_split(_p(a_s), _p(b_s), _p(out), _p(bias), M, N, K, a_s.stride(0), b_s.stride(0),
+                              out.stride(0), 1 if accumulate else 0, _p(ws), ws.numel() if ws is not None else 0,
+                              _stream()), "gemm_split")
+    return out
+
+
+def split_transpose(t, pro=None):
+    """sx8 [C, R] = split(pro(t)^T) for fp32 t [R, C] (R % 8 == 0); pro = Pro(act, mu, rs, gamma, beta) or None."""
+    _need_cuda(t)
+    t = _rows2d(t)
+    R, C = t.shape
+    out = torch.empty(C, R, dtype=torch.float32, device=t.device)
+    mu = rs = gamma = beta = None
+    act = ACT_NONE
+    if pro is not None:
+        if pro.drop_p:
+            raise RuntimeError("wf3d.split_transpose: dropout prologue not supported")
+        mu, rs, gamma, beta, act = pro.mu, pro.rs, pro.gamma, pro.beta, pro.act
+    check(_lib.load().wf3d_split_transpose(_p(t), R, C, t.stride(0), _p(mu), _p(rs), _p(gamma), _p(beta), act,
+                                           _p(out), _stream()), "split_transpose")
+    return out
