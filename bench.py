@@ -33,6 +33,7 @@ CONFIGS = {
     "cfg1": (1, 1024, 32),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA (never the 2:1-sparsity figure)
 SEED = 1234
 
 
@@ -61,40 +62,45 @@ def make_inputs(B, N, V, rank, device):
 
 
 class GemmTimer:
-    """HIP-event timing of the dominant kernel's launches (the 128x128 fp32-MFMA
-    GEMM tile of wf3d_gemm) inside the timed region, on the stream they are
-    launched on (torch's current stream)."""
+    """HIP-event timing of the dominant kernel's launches inside the timed region, on the
+    stream they are launched on (torch's current stream): the 128x128 GEMM tile of
+    wf3d_gemm_split (bf16x3 mode) or wf3d_gemm (fp32 mode), launches >= min_flops."""
 
     def __init__(self, min_flops):
         self.min_flops, self.recs = min_flops, []
 
-    def install(self, ops):
-        self._orig = ops.gemm
+    def _wrap(self, fn, dims):
         timer = self
 
-        def timed(a, b, layout, **kw):
-            if layout == ops.TN:
-                K, M = a.shape; N = b.shape[1]
-            elif layout == ops.NN:
-                M, K = a.shape; N = b.shape[1]
-            else:
-                M, K = a.shape; N = b.shape[0]
+        def timed(a, b, *args, **kw):
+            M, N, K = dims(a, b, *args)
             fl = 2.0 * M * N * K
             if fl < timer.min_flops:
-                return timer._orig(a, b, layout, **kw)
+                return fn(a, b, *args, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = timer._orig(a, b, layout, **kw)
+            out = fn(a, b, *args, **kw)
             e1.record()
             timer.recs.append((e0, e1, fl))
             return out
 
-        ops.gemm = timed
-        import wf3d.functional as F
-        F.ops.gemm = timed
+        return timed
 
-    def uninstall(self, ops):
-        ops.gemm = self._orig
+    def install(self, ops, split):
+        self._ops, self._orig = ops, (ops.gemm, ops.gemm_split)
+        if split:
+            ops.gemm_split = self._wrap(ops.gemm_split, lambda a, b: (a.shape[0], b.shape[0], a.shape[1]))
+        else:
+            def dims(a, b, layout):
+                if layout == ops.TN:
+                    return a.shape[1], b.shape[1], a.shape[0]
+                if layout == ops.NN:
+                    return a.shape[0], b.shape[1], a.shape[1]
+                return a.shape[0], b.shape[0], a.shape[1]
+            ops.gemm = self._wrap(ops.gemm, dims)
+
+    def uninstall(self):
+        self._ops.gemm, self._ops.gemm_split = self._orig
 
     def summary(self):
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.recs)
@@ -168,11 +174,17 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
+                    help="arithmetic of the large GEMMs (default: wf3d.config / WF3D_PRECISION = bf16x3)")
     args = ap.parse_args()
 
+    from wf3d import config
     from wf3d import dist as wd
     from wf3d import ops
     from models.PointCloudToWireframe import PointCloudToWireframe
+    if args.precision:
+        config.set_precision(args.precision)
+    split = config.precision() == "bf16x3"
 
     rank, world, device = wd.init_from_env("cuda")
     if world != args.gpus:
@@ -205,14 +217,14 @@ def main():
     for _ in range(args.warmup):
         step()
     timer = GemmTimer(min_flops=1e11)     # the encoder's twelve >=137-GFLOP GEMM launches per step
-    timer.install(ops)
+    timer.install(ops, split)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    timer.uninstall(ops)
+    timer.uninstall()
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -226,9 +238,17 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get("gemm_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(args.config + ("" if split else "_fp32"), {}).get("gemm_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if split:
+            # bf16x3: every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
+            peak, kern = BF16_MFMA_PEAK_TFLOPS, "gemm_kernel<2,2,2,2,NT,split> (128x128x32, 3 x v_mfma_f32_32x32x16_bf16 per k16)"
+            extra = {"executed_mfma_tflops": 3.0 * achieved, "executed_frac": 3.0 * achieved / peak,
+                     "note": "achieved = algorithmic 2MNK FLOP / time; the split algorithm issues 3 MFMA FLOP per algorithmic FLOP"}
+        else:
+            peak, kern = FP32_MFMA_PEAK_TFLOPS, "gemm_kernel<2,2,2,2> (128x128x32 v_mfma_f32_32x32x2_f32)"
+            extra = {}
         res = {
             "metric": "point-clouds/sec fwd+bwd",
             "value": B * world * args.steps / dt,
@@ -236,16 +256,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16x3" if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N}x8 clouds, max_vertices={V}, batch {B}/GPU, train-mode fwd+bwd, "
                                    f"edge-head dropout p={args.dropout}, counts=V",
                        "global_batch": B * world, "num_points": N, "max_vertices": V,
-                       "parallelism": f"dp{world}", "algorithmic_gflop_per_cloud": total_fl / 1e9},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "gemm_kernel<2,2,2,2> (128x128x32 v_mfma_f32_32x32x2_f32)",
+                       "parallelism": f"dp{world}", "algorithmic_gflop_per_cloud": total_fl / 1e9,
+                       "arithmetic": ("fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate "
+                                      "(outputs within 1e-4 of the fp32 reference); heads and edge MLP on fp32 MFMA")
+                       if split else "fp32 MFMA everywhere"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "kernel": kern,
                          "launches_timed": n_launch, "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
-                         "whole_step_tflops": total_fl * B * world * args.steps / dt / 1e12},
+                         "whole_step_tflops": total_fl * B * world * args.steps / dt / 1e12, **extra},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, N, V)

@@ -23,6 +23,8 @@
 // The LayerNorm-apply + ReLU/GELU (+dropout) of the *previous* layer is fused
 // into the staging pass of the activation operand, so normalised activations
 // are never written to HBM: only pre-LN z and per-row (mu, rstd) exist.
+#include <stdlib.h>
+
 #include "wf3d_common.h"
 
 namespace {
@@ -519,6 +521,12 @@ extern "C" int wf3d_gemm_split(const void* A_sx8, const void* B_sx8, float* C, c
                "wf3d_gemm_split: K, lda, ldb must be multiples of 8 (sx8 groups)");
     WF3D_CHECK(lda >= K && ldb >= K && ldc >= N, WF3D_ERR_ARG, "wf3d_gemm_split: leading dimension too small");
     WF3D_CHECK(((uintptr_t)A_sx8 % 16 == 0) && ((uintptr_t)B_sx8 % 16 == 0), WF3D_ERR_ARG, "wf3d_gemm_split: operands must be 16-byte aligned");
+    {
+        // LDS-DMA staged kernel for every shape it supports (WF3D_SPLIT_DMA=0 forces the register-staged one)
+        static const int use_dma = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 1; }();
+        if (use_dma && wf3d_gemm_split_dma_ok(M, N, K, lda, ldb))
+            return wf3d_gemm_split_dma(A_sx8, B_sx8, C, bias, M, N, K, lda, ldb, ldc, accumulate, ws, ws_bytes, stream);
+    }
     GemmParams p{};
     p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;

@@ -1,0 +1,216 @@
+// bf16x3 split-precision GEMM, LDS-DMA staged:  C[M,N] (+)= A·B^T (+ bias),
+// A = sx8[M,K], B = sx8[N,K]  (sx8: see split.hip / include/wf3d.h).
+//
+// Operands need no transformation on their way in, so tiles go global -> LDS with
+// `global_load_lds_dwordx4` (no VGPR staging, no ds_write): each wave-instruction
+// lands 8 rows x 128 B = 1 KiB contiguously.  The LDS image is therefore unpadded
+// [128 rows][128 B]; bank conflicts are removed by an XOR swizzle of the 16-B chunk
+// index, chunk' = chunk ^ ((row >> 1) & 7), applied on the per-lane SOURCE address
+// of the DMA and again on the fragment read (both-sides rule, cdna_hip_programming.md
+// §5.4 rule 21): the 16 lanes of every ds_read_b128 group then hit 16 distinct slots.
+// One 16-B chunk is exactly one MFMA fragment (8 consecutive k of one bf16 plane).
+//
+// Per k16 step a wave reads 2x2 (tiles) x 2 (hi, lo) fragments per operand and issues
+// 2x2x3 v_mfma_f32_32x32x16_bf16:  acc += al*bh + ah*bl + ah*bh  (fp32 accumulate).
+// Two LDS stages: the DMA of slice t+1 is issued before the MFMAs of slice t and is
+// waited for (vmcnt(0), emitted by __syncthreads) only after them.
+#include "wf3d_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SBK = 32;                 // floats (= 128 B = 32 split elements) per row slice
+constexpr int STILE = 128 * SBK;        // floats per operand tile (16 KB)
+
+struct SplitParams {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    int accumulate;
+    int ksplit, kt_per_split;
+    float* slab;
+    int nbm, nbn;
+};
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_split_dma_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * STILE];     // 64 KB: 2 stages x (A, B)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 128, n0 = (vid % p.nbn) * 128;
+    const int ktotal = p.K / SBK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    // DMA source pointers: instruction q of this wave fills tile rows (4*wave+q)*8 .. +7;
+    // lane -> row (lane>>3), destination chunk (lane&7), source chunk swizzled.  Rows past
+    // the matrix edge are clamped (their results are never stored).
+    const float* asrc[4];
+    const float* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk * 4;
+        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 4;
+    }
+    auto issue = [&](int kt, int stage) {
+        float* As = smem + stage * 2 * STILE + wave * 4 * 8 * SBK;
+        float* Bs = As + STILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dma16(asrc[q] + kt * SBK, As + q * 8 * SBK);
+            dma16(bsrc[q] + kt * SBK, Bs + q * 8 * SBK);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addressing: row = tile*32 + l31 -> swizzle term depends on l31 only
+    const int fsw = (l31 >> 1) & 7;
+    if (kt0 < kt1) issue(kt0, 0);
+    __syncthreads();
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
+        const float* As = smem + stage * 2 * STILE;
+        const float* Bs = As + STILE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int phi = ((2 * (2 * s2 + h)) ^ fsw) * 4, plo = phi ^ 4;     // float offsets of the hi / lo chunk
+            f32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* pr = As + ((wm * 2 + i) * 32 + l31) * SBK;
+                ah[i] = *reinterpret_cast<const f32x4*>(pr + phi);
+                al[i] = *reinterpret_cast<const f32x4*>(pr + plo);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* pr = Bs + ((wn * 2 + j) * 32 + l31) * SBK;
+                bh[j] = *reinterpret_cast<const f32x4*>(pr + phi);
+                bl[j] = *reinterpret_cast<const f32x4*>(pr + plo);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();        // vmcnt(0) for the DMA of slice kt+1, and WAR protection of this stage
+        stage ^= 1;
+    }
+
+    const bool split = p.ksplit > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wn * 2 + j) * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v += bv;
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
+    const size_t total = (size_t)p.M * p.N;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / p.N), col = (int)(idx % p.N);
+        float v = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) v += p.slab[(size_t)z * total + idx];
+        if (p.bias) v += p.bias[col];
+        float* c = p.C + (size_t)row * p.ldc + col;
+        if (p.accumulate) v += *c;
+        *c = v;
+    }
+}
+
+void plan(int M, int N, int K, int& ksplit, int& kt_per) {
+    const long tiles = (long)wf3d_cdiv(M, 128) * wf3d_cdiv(N, 128);
+    const int ktotal = K / SBK;
+    ksplit = 1; kt_per = ktotal;
+    if (tiles >= 256 || ktotal < 8) return;
+    int want = (int)((512 + tiles - 1) / tiles);
+    int ks = want < ktotal / 4 ? want : ktotal / 4;
+    if (ks > 64) ks = 64;
+    if (ks < 2) return;
+    kt_per = wf3d_cdiv(ktotal, ks);
+    ksplit = wf3d_cdiv(ktotal, kt_per);
+}
+
+}  // namespace
+
+// Returns 1 when the DMA kernel can take the problem (K a multiple of the 32-wide slice,
+// 16-B aligned rows); the register-staged kernel in gemm.hip handles everything else.
+extern "C" int wf3d_gemm_split_dma_ok(int M, int N, int K, int lda, int ldb) {
+    return M > 0 && N > 0 && K >= SBK && K % SBK == 0 && lda % 4 == 0 && ldb % 4 == 0;
+}
+
+extern "C" size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int ks, per;
+    plan(M, N, K, ks, per);
+    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+}
+
+extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N,
+                                   int K, int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    WF3D_CHECK(wf3d_gemm_split_dma_ok(M, N, K, lda, ldb), WF3D_ERR_UNSUPPORTED, "wf3d_gemm_split_dma: shape not supported");
+    WF3D_CHECK(A_sx8 && B_sx8 && C, WF3D_ERR_ARG, "wf3d_gemm_split_dma: null operand");
+    WF3D_CHECK(lda >= K && ldb >= K && ldc >= N, WF3D_ERR_ARG, "wf3d_gemm_split_dma: leading dimension too small");
+    WF3D_CHECK(((uintptr_t)A_sx8 % 16 == 0) && ((uintptr_t)B_sx8 % 16 == 0), WF3D_ERR_ARG, "wf3d_gemm_split_dma: misaligned operand");
+    SplitParams p{};
+    p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
+    p.nbm = wf3d_cdiv(M, 128); p.nbn = wf3d_cdiv(N, 128);
+    plan(M, N, K, p.ksplit, p.kt_per_split);
+    const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
+    if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
+    p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_split_dma_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
+    WF3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        WF3D_LAUNCH_CHECK();
+    }
+    return WF3D_OK;
+}

@@ -30,6 +30,12 @@ void wf3d_set_error(const char* fmt, ...);
         }                                                                     \
     } while (0)
 
+// internal (not part of include/wf3d.h): LDS-DMA variant of the split GEMM, gemm_split.hip
+extern "C" int wf3d_gemm_split_dma_ok(int M, int N, int K, int lda, int ldb);
+extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N,
+                                   int K, int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes,
+                                   void* stream);
+
 static inline int wf3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers --------------------------------------------------------
