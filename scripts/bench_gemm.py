@@ -30,11 +30,13 @@ for K, N in layers:
     cases.append((f"SPLIT NT K={K} N={N}", lambda Xs=Xs, Ws=Ws, o=o_nt: ops.gemm_split(Xs, Ws, out=o), fl))
     cases.append((f"SPLIT dgrad K={N} N={K}", lambda Gs=Gs, WTs=WTs, o=o_nn: ops.gemm_split(Gs, WTs, out=o), fl))
     cases.append((f"TN+pro K={M} out={N}x{K}", lambda G=G, X=X, pro=pro, o=o_tn: ops.gemm(G, X, ops.TN, pro=pro, out=o), fl))
+if os.environ.get("ONLY"):
+    cases = [c for c in cases if os.environ["ONLY"] in c[0]]
 times = {c[0]: [] for c in cases}
 for c in cases:
     c[1]()
 torch.cuda.synchronize()
-for r in range(5):
+for r in range(int(os.environ.get("ROUNDS", 5))):
     for name, fn, fl in cases:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -14,6 +14,8 @@
 // 2x2x3 v_mfma_f32_32x32x16_bf16:  acc += al*bh + ah*bl + ah*bh  (fp32 accumulate).
 // Two LDS stages: the DMA of slice t+1 is issued before the MFMAs of slice t and is
 // waited for (vmcnt(0), emitted by __syncthreads) only after them.
+#include <stdlib.h>
+
 #include "wf3d_common.h"
 
 namespace {
@@ -146,6 +148,174 @@ __global__ __launch_bounds__(256, 2) void gemm_split_dma_kernel(const SplitParam
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Deep-pipelined variant: 256x128 tile, 8 waves (4 x 2, 64x64 each), THREE LDS
+// stages (144 KB, one workgroup per CU, two waves per SIMD).  The DMA of slice
+// t+2 is issued before the MFMAs of slice t and stays in flight across the
+// barrier: a counted `s_waitcnt vmcnt(6)` (the 6 youngest = slice t+2's pieces)
+// retires slice t+1 only, and a raw s_barrier publishes it (never __syncthreads,
+// whose fence would drain vmcnt to 0 — cdna_hip_programming.md "Pipelining
+// across barriers").  The 2-stage kernel above stalls every slice for the DMA
+// latency (issue -> landed ~1-2k cycles vs 768 MFMA cycles per slice).
+// ---------------------------------------------------------------------------
+constexpr int T3_A = 256 * SBK, T3_B = 128 * SBK, T3_STAGE = T3_A + T3_B;
+
+struct Frag { f32x4 ah[2], al[2], bh[2], bl[2]; };
+
+__device__ __forceinline__ void load_frag(Frag& f, const float* As, const float* Bs, int wm, int wn, int l31, int h,
+                                          int fsw, int s2) {
+    const int phi = ((2 * (2 * s2 + h)) ^ fsw) * 4, plo = phi ^ 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* pr = As + ((wm * 2 + i) * 32 + l31) * SBK;
+        f.ah[i] = *reinterpret_cast<const f32x4*>(pr + phi);
+        f.al[i] = *reinterpret_cast<const f32x4*>(pr + plo);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* pr = Bs + ((wn * 2 + j) * 32 + l31) * SBK;
+        f.bh[j] = *reinterpret_cast<const f32x4*>(pr + phi);
+        f.bl[j] = *reinterpret_cast<const f32x4*>(pr + plo);
+    }
+}
+
+// 12 MFMAs of one k16 step; DMA pieces P0, P0+1, P0+2 of the slice two ahead are issued one
+// at a time after the 3rd, 6th and 9th MFMA (pieces 0..3 = A rows, 4..5 = B rows).
+template <int P0>
+__device__ __forceinline__ void mma12(f32x16 (&acc)[2][2], const Frag& f, bool ahead, const float* const (&asrc)[4],
+                                      const float* const (&bsrc)[2], int kn, float* dA, float* dB) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+            if (i * 2 + j < 3) {
+                constexpr int dummy = 0; (void)dummy;
+                const int piece = P0 + i * 2 + j;
+                __builtin_amdgcn_sched_barrier(0);
+                if (ahead) {
+                    if (piece < 4) dma16(asrc[piece < 4 ? piece : 0] + kn, dA + piece * 8 * SBK);
+                    else           dma16(bsrc[piece >= 4 ? piece - 4 : 0] + kn, dB + (piece - 4) * 8 * SBK);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+
+__global__ __launch_bounds__(512, 2) void gemm_split_dma3_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * T3_STAGE];      // 147,456 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 128;
+    const int ktotal = p.K / SBK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    const float* asrc[4];
+    const float* bsrc[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 8 + (lane >> 3);
+        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 4;
+    }
+    auto issue = [&](int kt, int stage) {
+        float* As = smem + stage * T3_STAGE + wave * 4 * 8 * SBK;
+        float* Bs = smem + stage * T3_STAGE + T3_A + wave * 2 * 8 * SBK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16(asrc[q] + kt * SBK, As + q * 8 * SBK);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16(bsrc[q] + kt * SBK, Bs + q * 8 * SBK);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fsw = (l31 >> 1) & 7;
+    if (kt0 < kt1) issue(kt0, 0);
+    if (kt0 + 1 < kt1) {
+        issue(kt0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // Measured alternatives that LOST on this structure (same shapes, same process): a half-slice
+    // stagger of waves 4-7 against their SIMD partners (-11 %: duplicated bodies, +70 VGPRs) and
+    // fetching both k16 steps' fragments up front (-4 %).  Bunching the 6 DMA pieces at the loop
+    // top instead of spreading them between MFMA groups: -7 %.
+    Frag X, Y;
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool ahead = kt + 2 < kt1;
+        const int nstage = stage == 0 ? 2 : stage - 1;                   // (stage + 2) % 3
+        float* dA = smem + nstage * T3_STAGE + wave * 4 * 8 * SBK;
+        float* dB = smem + nstage * T3_STAGE + T3_A + wave * 2 * 8 * SBK;
+        const int kn = (kt + 2) * SBK;
+        const float* As = smem + stage * T3_STAGE;
+        const float* Bs = As + T3_A;
+        load_frag(X, As, Bs, wm, wn, l31, h, fsw, 0);
+        mma12<0>(acc, X, ahead, asrc, bsrc, kn, dA, dB);
+        load_frag(Y, As, Bs, wm, wn, l31, h, fsw, 1);
+        mma12<3>(acc, Y, ahead, asrc, bsrc, kn, dA, dB);
+        // retire slice kt+1 (all but the 6 youngest DMA pieces), make sure this wave's LDS reads
+        // of slice kt are done (lgkmcnt) before anyone may overwrite the stage, then publish.
+        if (ahead) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    const bool split = p.ksplit > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wn * 2 + j) * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v += bv;
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
     const size_t total = (size_t)p.M * p.N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -159,8 +329,14 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) 
     }
 }
 
+int split_variant() {          // WF3D_SPLIT_DMA: 3 (default) = 256x128 3-stage, 2 = 128x128 2-stage
+    static const int v = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 3; }();
+    return v;
+}
+
 void plan(int M, int N, int K, int& ksplit, int& kt_per) {
-    const long tiles = (long)wf3d_cdiv(M, 128) * wf3d_cdiv(N, 128);
+    const int bm = split_variant() == 3 ? 256 : 128;
+    const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, 128);
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
     if (tiles >= 256 || ktotal < 8) return;
@@ -197,13 +373,15 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     SplitParams p{};
     p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
-    p.nbm = wf3d_cdiv(M, 128); p.nbn = wf3d_cdiv(N, 128);
+    const bool deep = split_variant() == 3;
+    p.nbm = wf3d_cdiv(M, deep ? 256 : 128); p.nbn = wf3d_cdiv(N, 128);
     plan(M, N, K, p.ksplit, p.kt_per_split);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_split_dma_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
+    if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    else      hipLaunchKernelGGL(gemm_split_dma_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const size_t total = (size_t)M * N;

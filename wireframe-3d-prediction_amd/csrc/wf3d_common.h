@@ -32,6 +32,7 @@ void wf3d_set_error(const char* fmt, ...);
 
 // internal (not part of include/wf3d.h): LDS-DMA variant of the split GEMM, gemm_split.hip
 extern "C" int wf3d_gemm_split_dma_ok(int M, int N, int K, int lda, int ldb);
+extern "C" size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K);
 extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N,
                                    int K, int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes,
                                    void* stream);
