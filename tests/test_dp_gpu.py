@@ -1,0 +1,102 @@
+"""Data-parallel equivalence on the real model: two ranks (sharing the one GPU of the test
+box through the gloo backend — RCCL refuses two ranks on one device) each run half of a
+batch through PointCloudToWireframe on the HIP path and average gradients with
+wf3d.dist.GradReducer; the result must equal the single-process gradient of the whole
+batch (no cross-sample statistic anywhere in the path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+import helpers as H  # noqa: E402,F401
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _inputs(B, N, V):
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, N, 8, generator=g)
+    x[1, N // 2:] = 0
+    counts = torch.tensor([V, 3, V - 1, 2][:B])
+    cot = {"vertices": torch.randn(B, V, 3, generator=g), "existence_probabilities": torch.randn(B, V, generator=g),
+           "edge_probs": torch.randn(B, V * (V - 1) // 2, generator=g)}
+    return x, counts, cot
+
+
+def _run(model, x, counts, cot, dev, inv):
+    out = model(x.to(dev), counts.to(dev))
+    E = out["edge_probs"].shape[1]
+    loss = sum((out[k] * cot[k][..., :E].to(dev) if k == "edge_probs" else out[k] * cot[k].to(dev)).sum()
+               for k in cot) * inv
+    loss.backward()
+
+
+def _worker(rank, world, port, B, N, V, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), WF3D_DIST_BACKEND="gloo")
+    from wf3d import dist as wd
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    r, w, dev = wd.init_from_env("cuda")
+    torch.manual_seed(1000 + rank)                  # ranks start from DIFFERENT weights
+    model = PointCloudToWireframe(8, V).to(dev).set_dropout(0.0)
+    model.vertex_predictor.ensure_point_pool_proj(1024, dev)
+    wd.sync_parameters(model)                        # ... and are made identical here
+    model.train()
+    red = wd.GradReducer(model)
+    x, counts, cot = _inputs(B, N, V)
+    lo, hi = wd.shard_batch(B, rank, world)
+    for step in range(2):                            # second step exercises the learned `expect` counts
+        model.zero_grad(set_to_none=True)
+        _run(model, x[lo:hi], counts[lo:hi], {k: v[lo:hi] for k, v in cot.items()}, dev, 1.0 / (hi - lo))
+        red.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
+        # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
+        q.put({n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None})
+        q.put({n: p.detach().cpu().numpy() for n, p in model.named_parameters()})
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process_batch():
+    B, N, V = 4, 160, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, N, V, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads = q.get(timeout=300)
+    params = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    dev = torch.device("cuda:0")
+    model = PointCloudToWireframe(8, V).to(dev).set_dropout(0.0)
+    model.vertex_predictor.ensure_point_pool_proj(1024, dev)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(params[n]))
+    model.train()
+    x, counts, cot = _inputs(B, N, V)
+    # mean over the two shards of (shard loss / shard size) == whole-batch loss / B for equal shards
+    _run(model, x, counts, cot, dev, 1.0 / B)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert n not in grads
+            continue
+        a, b = torch.from_numpy(grads[n]).double(), p.grad.detach().cpu().double()
+        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
+    assert worst < 2e-3, worst

@@ -24,6 +24,7 @@ def init_from_env(device_type=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = (device_type or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
     if use_cuda:
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -31,7 +32,9 @@ def init_from_env(device_type=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl" if use_cuda else "gloo", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  WF3D_DIST_BACKEND=gloo lets several ranks share one GPU (tests).
+        backend = os.environ.get("WF3D_DIST_BACKEND", "nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
