@@ -103,16 +103,18 @@ int wf3d_gemm_split(const void* A_sx8, const void* B_sx8, float* C, const float*
 /* out_sx8[r, c] = split(in[r*row_stride + c*col_stride])  (col_stride 1: convert;
  * row_stride 1: transpose-convert, used for W^T) */
 int wf3d_split_rows(const float* in, long row_stride, long col_stride, int R, int C, void* out_sx8, void* stream);
-/* out_sx8[C, R] = split(act(LN-affine(in[R, C])))^T — the wgrad operands (reduction
+/* out_sx8[C, R] = split(drop(act(LN-affine(in[R, C]))))^T — the wgrad operands (reduction
  * index = row index made contiguous): dW = dY^T·X becomes the NT-form
- * wf3d_gemm_split(dY^T_sx8, X^T_sx8).  mu/gamma NULL skip the respective part. */
+ * wf3d_gemm_split(dY^T_sx8, X^T_sx8).  mu/gamma NULL skip the respective part;
+ * in_sx8 != 0: `in` is itself an sx8 matrix (no prologue), transposed plane-wise. */
 int wf3d_split_transpose(const float* in, int R, int C, int ld, const float* mu, const float* rs,
-                         const float* gamma, const float* beta, int act, void* out_sx8, void* stream);
-/* LayerNorm statistics of z[R,D] AND h = act(LN(z)) in sx8, one read of z:
+                         const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
+                         int in_sx8, void* out_sx8, void* stream);
+/* LayerNorm statistics of z[R,D] AND h = drop(act(LN(z))) in sx8, one read of z:
  * the operand producer between two split GEMMs (replaces native_layer_norm +
  * relu_ of PointNetEncoder.py:36-38 in the split path). */
 int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, const float* beta, int act, float eps,
-                 float* mu, float* rs, void* h_sx8, void* stream);
+                 float drop_p, uint32_t drop_seed, float* mu, float* rs, void* h_sx8, void* stream);
 
 /* ------------------------------------------------------------------------
  * LayerNorm pieces (nn.LayerNorm, eps 1e-5, biased variance — SURVEY App. A)
@@ -131,8 +133,8 @@ int wf3d_ln_act_apply(const float* z, int R, int D, const float* mu, const float
 /* Backward of h = drop(act(LN(z))) given dh: writes dz (may alias dh) and the
  * column reductions dgamma[D], dbeta[D] (LayerNorm affine grads) and
  * dbias[D] = sum_r dz[r,:] (the preceding Linear's bias grad).  Any of the
- * three outputs may be NULL; dz_sx8 (optional) receives dz a second time in the
- * sx8 split format for wf3d_gemm_split.  Replaces native_layer_norm_backward +
+ * three outputs may be NULL; dz_sx8 (optional) receives dz in the sx8 split format
+ * for wf3d_gemm_split, and then dz itself may be NULL.  Replaces native_layer_norm_backward +
  * threshold_backward / gelu_backward + the bias sum. */
 size_t wf3d_ln_act_bwd_ws_bytes(int R, int D);
 int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, const float* mu, const float* rs,

@@ -329,6 +329,9 @@ def test_ln_prep_and_bwd_split_output(ops, act, R, D):
     dh_, dl_ = unpack_sx8(ds)
     eh, el = ref_split(dz)
     assert torch.equal(dh_, eh) and torch.equal(dl_, el)                 # sx8 copy of dz is the exact split of dz
+    ds2 = torch.zeros_like(Z)
+    none, dg2, _, _ = ops.ln_act_bwd(dh, Z, mu, rs, gamma, beta, act, dz_split=ds2, want_dz=False)
+    assert none is None and torch.equal(ds2, ds)                         # fp32 dz not written, sx8 identical
 
 
 @pytest.mark.parametrize("act", [0, 1])
@@ -344,6 +347,9 @@ def test_split_transpose_and_wgrad_form(ops, act, R, C):
     ph, pl = unpack_sx8(ops.split_transpose(Z, pro))
     want = ref64(lambda z, g, b: ln_ref(z, g, b, act), Z, gamma, beta)
     assert rel((ph + pl).T, want) < 2e-5
+    if C % 8 == 0:
+        sh, sl = unpack_sx8(ops.split_transpose(ops.split_rows(Z), in_sx8=True))     # sx8 -> sx8 transpose
+        assert torch.equal(sh + sl, (rh + rl).T)
     # wgrad: dW[N, C] = G^T · act(LN(Z))  via NT-form split GEMM on the transposed operands
     N = 96
     G = rnd(R, N, seed=5)

@@ -58,7 +58,7 @@ def test_small_encoder_vs_golden(precision):
 
 
 @pytest.mark.parametrize("V", [7, 2])
-def test_small_edge_vs_golden(V):
+def test_small_edge_vs_golden(V, precision):
     from models.EdgePredictor import EdgePredictor
     gold = H.load_golden("small_edge")
     shapes = H.sub_shapes("edge_predictor.", edge_hidden=64)
@@ -194,14 +194,14 @@ def test_dropout_train_mode_runs_and_is_seeded():
     assert torch.equal(e1, e2)
 
 
-def test_edge_head_dropout_gradcheck():
+def test_edge_head_dropout_gradcheck(precision):
     """Directional finite-difference check of EdgeFn backward WITH dropout masks on."""
     from models.EdgePredictor import EdgePredictor
     torch.manual_seed(3)
     ep = EdgePredictor(3, 64, 2).to(dev())
     ep.train()
     v = torch.randn(3, 6, 3, device=dev()).requires_grad_()
-    counts = [6, 3, 5]
+    counts = [6, 3, 6]                     # 15 + 3 + 15 = 33 edge rows... keep one ragged sample
     cot = torch.randn(3, 15, device=dev())
 
     def run(vv):

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
                     o[j] = has_ln ? r * (g * gam[i][j] - c1 - x * c2) : g;
                     a_dg[i][j] += g * x; a_db[i][j] += g; a_dbias[i][j] += o[j];
                 }
-                *reinterpret_cast<f32x4*>(dz + (size_t)row * D + c) = o;
+                if (dz) *reinterpret_cast<f32x4*>(dz + (size_t)row * D + c) = o;
                 if (dz_sx8) {
                     // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts,
                     // odd lane the 8 low parts, after swapping the halves they do not own
@@ -274,7 +274,7 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
         if (dbias) hipMemsetAsync(dbias, 0, D * sizeof(float), st);
         return WF3D_OK;
     }
-    WF3D_CHECK(dh && z && dz, WF3D_ERR_ARG, "wf3d_ln_act_bwd: null pointer");
+    WF3D_CHECK(dh && z && (dz || dz_sx8), WF3D_ERR_ARG, "wf3d_ln_act_bwd: null pointer");
     WF3D_CHECK(((uintptr_t)dh % 16 == 0) && ((uintptr_t)z % 16 == 0) && ((uintptr_t)dz % 16 == 0) &&
                (!gamma || ((uintptr_t)gamma % 16 == 0 && (uintptr_t)beta % 16 == 0)),
                WF3D_ERR_ARG, "wf3d_ln_act_bwd: pointers must be 16-byte aligned");

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 template <int NS>
 __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ z, int R, int D,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int act, float eps, float* __restrict__ mu, float* __restrict__ rs,
+                                                       int act, float eps, uint32_t seed, uint32_t thresh, float dscale,
+                                                       float* __restrict__ mu, float* __restrict__ rs,
                                                        float* __restrict__ h_sx8) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -90,6 +91,11 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
                 o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * g0[j] + b0[j]);
                 o[4 + j] = wf3d_act_rt(act, (v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
             }
+            if (thresh) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = wf3d_keep(seed, (uint32_t)row, (uint32_t)(c + j), thresh) ? o[j] * dscale : 0.f;
+            }
             store_sx8(h_sx8 + (size_t)row * D + c, o);
         }
     }
@@ -104,11 +110,29 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
                                                                const float* __restrict__ mu, const float* __restrict__ rs,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int act,
-                                                               float* __restrict__ out) {
+                                                               uint32_t seed, uint32_t thresh, float dscale,
+                                                               int in_sx8, float* __restrict__ out) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int t = threadIdx.x;
-    {
+    if (in_sx8) {
+        // input already split (e.g. dz written by ln_act_bwd): rebuild v = hi + lo (exact in fp32)
+        const int g = t & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = (t >> 3) + 32 * i;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (r0 + rr < R && c0 + g * 8 < C) {
+                const float* p = in + (size_t)(r0 + rr) * ld + c0 + g * 8;
+                const bf16x8 hi = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(p));
+                const bf16x8 lo = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(p + 4));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[rr][g * 8 + j] = v[j];
+        }
+    } else {
         const int cc = (t & 15) * 4;
         f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (gamma && c0 + cc < C) { g = *reinterpret_cast<const f32x4*>(gamma + c0 + cc); b = *reinterpret_cast<const f32x4*>(beta + c0 + cc); }
@@ -129,6 +153,11 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* __res
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = wf3d_act_rt(act, v[j]);
+                if (thresh) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = wf3d_keep(seed, (uint32_t)(r0 + rr), (uint32_t)(c0 + cc + j), thresh) ? v[j] * dscale : 0.f;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) tile[rr][cc + j] = v[j];
@@ -164,7 +193,10 @@ extern "C" int wf3d_split_rows(const float* in, long row_stride, long col_stride
 }
 
 extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, const float* beta, int act, float eps,
-                            float* mu, float* rs, void* h_sx8, void* stream) {
+                            float drop_p, uint32_t drop_seed, float* mu, float* rs, void* h_sx8, void* stream) {
+    WF3D_CHECK(drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_ln_prep: bad drop_p");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float dscale = 1.0f / (1.0f - drop_p);
     WF3D_CHECK(R >= 0 && D > 0, WF3D_ERR_ARG, "wf3d_ln_prep: bad dims");
     WF3D_CHECK(D % 8 == 0 && D <= 4096, WF3D_ERR_UNSUPPORTED, "wf3d_ln_prep: D=%d must be a multiple of 8, <= 4096", D);
     WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_ln_prep: bad act");
@@ -176,7 +208,7 @@ extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, co
     hipStream_t st = (hipStream_t)stream;
 #define WF3D_LP(NS_)                                                                                              \
     hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(wf3d_cdiv(R, 4)), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
-                       mu, rs, (float*)h_sx8)
+                       drop_seed, thresh, dscale, mu, rs, (float*)h_sx8)
     if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
 #undef WF3D_LP
     WF3D_LAUNCH_CHECK();
@@ -184,8 +216,14 @@ extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, co
 }
 
 extern "C" int wf3d_split_transpose(const float* in, int R, int C, int ld, const float* mu, const float* rs,
-                                    const float* gamma, const float* beta, int act, void* out_sx8, void* stream) {
+                                    const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
+                                    int in_sx8, void* out_sx8, void* stream) {
+    WF3D_CHECK(drop_p >= 0.f && drop_p < 1.f && (!in_sx8 || drop_p == 0.f), WF3D_ERR_ARG, "wf3d_split_transpose: bad drop_p");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float dscale = 1.0f / (1.0f - drop_p);
     WF3D_CHECK(R > 0 && C > 0 && ld >= C, WF3D_ERR_ARG, "wf3d_split_transpose: bad dims");
+    WF3D_CHECK(!in_sx8 || (C % 8 == 0 && ld % 8 == 0 && !mu && !gamma && act == 0), WF3D_ERR_UNSUPPORTED,
+               "wf3d_split_transpose: an sx8 input needs C %% 8 == 0 and takes no prologue");
     WF3D_CHECK(R % 8 == 0 && C % 4 == 0 && ld % 4 == 0, WF3D_ERR_UNSUPPORTED,
                "wf3d_split_transpose: R %% 8, C %% 4 and ld %% 4 must be 0 (R=%d C=%d ld=%d)", R, C, ld);
     WF3D_CHECK(in && out_sx8 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out_sx8 % 16 == 0), WF3D_ERR_ARG,
@@ -196,7 +234,8 @@ extern "C" int wf3d_split_transpose(const float* in, int R, int C, int ld, const
     WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_split_transpose: bad act");
     WF3D_CHECK(wf3d_cdiv(R, 64) <= 65535, WF3D_ERR_UNSUPPORTED, "wf3d_split_transpose: too many rows");
     hipLaunchKernelGGL(split_transpose_kernel, dim3(wf3d_cdiv(C, 64), wf3d_cdiv(R, 64)), dim3(256), 0,
-                       (hipStream_t)stream, in, R, C, ld, mu, rs, gamma, beta, act, (float*)out_sx8);
+                       (hipStream_t)stream, in, R, C, ld, mu, rs, gamma, beta, act, drop_seed, thresh, dscale, in_sx8,
+                       (float*)out_sx8);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

@@ -9,6 +9,7 @@ serial per-sample loop."""
 import torch
 import torch.nn as nn
 
+from wf3d import config
 from wf3d.functional import EdgeFn, edge_index_lists
 
 
@@ -60,7 +61,8 @@ class EdgePredictor(nn.Module):
             raise IndexError("too many indices for tensor of dimension 1")
         ps = self._dropout_ps()
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) if any(ps) else 0
-        return EdgeFn.apply(vertices.float(), tuple(counts), self._heads, ps, seed, *self._param_list())
+        return EdgeFn.apply(vertices.float(), tuple(counts), self._heads, ps, seed, config.precision(),
+                            *self._param_list())
 
     def forward(self, vertices):
         b, v, _ = vertices.shape

@@ -138,8 +138,10 @@ class EncoderFn(torch.autograd.Function):
                 mu, rs = stats[i]
                 want_s = i > 0 and _split_ok(M, W.shape[0], split)
                 dz_s = torch.empty_like(dh) if want_s else None
+                # with both consumers (dgrad, wgrad) on the split path the fp32 dz is never needed
+                all_split = want_s and _split_ok(M, W.shape[1], split) and M % 8 == 0
                 dz, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1] = ops.ln_act_bwd(
-                    dh, zs[i], mu, rs, g, be, ACT_RELU, inplace=True, dz_split=dz_s)
+                    dh, zs[i], mu, rs, g, be, ACT_RELU, inplace=True, dz_split=dz_s, want_dz=not all_split)
             else:
                 grads[4 * i + 1] = ops.colsum(dz)
                 if nh and _split_ok(M, W.shape[0], split):
@@ -152,7 +154,7 @@ class EncoderFn(torch.autograd.Function):
             K = W.shape[1]
             if i > 0 and dz_s is not None and _split_ok(M, K, split) and M % 8 == 0:
                 # wgrad dW = dz^T · h_prev as an NT-form split GEMM over the point index
-                grads[4 * i] = ops.gemm_split(ops.split_transpose(dz), ops.split_transpose(a_prev, pro_prev))
+                grads[4 * i] = ops.gemm_split(ops.split_transpose(dz_s, in_sx8=True), ops.split_transpose(a_prev, pro_prev))
             else:
                 grads[4 * i] = ops.gemm(dz, a_prev, TN, pro=pro_prev)
             if i > 0:
@@ -254,7 +256,7 @@ class EdgeFn(torch.autograd.Function):
     (vertex_proj.{0,1,3,4}, attention.{in_proj,out_proj}, edge_mlp.{0,1,4,5,8,10})"""
 
     @staticmethod
-    def forward(ctx, verts, counts, heads, drop_ps, seed, *params):
+    def forward(ctx, verts, counts, heads, drop_ps, seed, precision, *params):
         (P0w, P0b, P1g, P1b, P3w, P3b, P4g, P4b, Aw, Ab, Ow, Ob,
          M0w, M0b, M1g, M1b, M4w, M4b, M5g, M5b, M8w, M8b, M10w, M10b) = params
         B, V, _ = verts.shape
@@ -276,11 +278,22 @@ class EdgeFn(torch.autograd.Function):
         ops.gemm(cv, Wd, NT, out=Pb, accumulate=True)
         pre, mu0, rs0, delta = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta)
         del Pa, Pb
-        z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])); s2 = ops.row_stats(z2)
-        z3 = ops.gemm(z2, M8w, NT, bias=M8b, pro=Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3]))
+        # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
+        split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
+        if split:
+            mu0, rs0, h1 = ops.ln_prep(pre, M1g, M1b, ACT_GELU, drop_p=p1_, seed=sd[2])
+            z2 = ops.gemm_split(h1, ops.split_rows(M4w), bias=M4b)
+            mu2, rs2, h2 = ops.ln_prep(z2, M5g, M5b, ACT_GELU, drop_p=p2_, seed=sd[3])
+            s2 = (mu2, rs2)
+            z3 = ops.gemm_split(h2, ops.split_rows(M8w), bias=M8b)
+            del h1, h2
+        else:
+            z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])); s2 = ops.row_stats(z2)
+            z3 = ops.gemm(z2, M8w, NT, bias=M8b, pro=Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3]))
         logit = ops.gemm(z3, M10w, NT, bias=M10b, pro=Pro(ACT_GELU))
         probs = ops.edge_prob_fwd(logit, meta)
         ctx.params, ctx.cfg = params, (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
+        ctx.split = split
         ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3)
         ctx.save_for_backward(probs)
         return probs
@@ -297,12 +310,29 @@ class EdgeFn(torch.autograd.Function):
         dlogit = ops.edge_prob_bwd(probs, dprobs.contiguous(), meta)                      # [Re,1]
         G[23] = ops.colsum(dlogit)
         G[22], dh3 = _lin_bwd(dlogit, z3, M10w, Pro(ACT_GELU))
-        dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True)
         p2 = Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3])
-        G[20], dh2 = _lin_bwd(dz3, z2, M8w, p2)
-        dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3], inplace=True)
         p1 = Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])
-        G[16], dh1 = _lin_bwd(dz2, pre, M4w, p1)
+        tsplit = ctx.split and meta.Re % 8 == 0              # wgrad operands need whole 8-row groups
+        if ctx.split:
+            dz3_s = torch.empty_like(dh3)
+            dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True,
+                                              dz_split=dz3_s, want_dz=not tsplit)
+            G[20] = (ops.gemm_split(ops.split_transpose(dz3_s, in_sx8=True), ops.split_transpose(z2, p2)) if tsplit
+                     else ops.gemm(dz3, z2, TN, pro=p2))
+            dh2 = ops.gemm_split(dz3_s, ops.split_rows(M8w, transpose=True))
+            del dz3, dz3_s
+            dz2_s = torch.empty_like(dh2)
+            dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3],
+                                                      inplace=True, dz_split=dz2_s, want_dz=not tsplit)
+            G[16] = (ops.gemm_split(ops.split_transpose(dz2_s, in_sx8=True), ops.split_transpose(pre, p1)) if tsplit
+                     else ops.gemm(dz2, pre, TN, pro=p1))
+            dh1 = ops.gemm_split(dz2_s, ops.split_rows(M4w, transpose=True))
+            del dz2, dz2_s
+        else:
+            dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True)
+            G[20], dh2 = _lin_bwd(dz3, z2, M8w, p2)
+            dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3], inplace=True)
+            G[16], dh1 = _lin_bwd(dz2, pre, M4w, p1)
         dpre, G[14], G[15], _ = ops.ln_act_bwd(dh1, pre, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], want_bias=False, inplace=True)
         # split first layer backward
         dW0 = torch.zeros_like(M0w)
@@ -334,7 +364,7 @@ class EdgeFn(torch.autograd.Function):
         ops.gemm(dza, P0w, NN, out=dcv, accumulate=True)
         dverts = ops.edge_scatter_dverts(dcv, meta, B, V)
         ctx.saved = None
-        return (dverts, None, None, None, None, *G)
+        return (dverts, None, None, None, None, None, *G)
 
 
 def edge_index_lists(counts, _cache={}):

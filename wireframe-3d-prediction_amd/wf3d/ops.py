@@ -145,13 +145,16 @@ def ln_act_apply(z, mu, rs, gamma, beta, act, addend=None, drop_p=0.0, seed=0, o
 
 
 def ln_act_bwd(dh, z, mu, rs, gamma, beta, act, drop_p=0.0, seed=0, want_affine=True, want_bias=True, inplace=False,
-               dz_split=None):
-    """Returns (dz, dgamma, dbeta, dbias); `dz_split` (optional sx8 buffer) also receives dz."""
+               dz_split=None, want_dz=True):
+    """Returns (dz, dgamma, dbeta, dbias); `dz_split` (optional sx8 buffer) also receives dz, and
+    with want_dz=False the fp32 dz is not written at all (returned as None)."""
     _need_cuda(dh, z, mu, rs, gamma, beta)
     if not (dh.is_contiguous() and z.is_contiguous()):
         raise RuntimeError("wf3d.ln_act_bwd: contiguous tensors required")
     R, D = z.shape
-    dz = dh if inplace else torch.empty_like(z)
+    if not want_dz and dz_split is None:
+        raise RuntimeError("wf3d.ln_act_bwd: want_dz=False needs dz_split")
+    dz = None if not want_dz else (dh if inplace else torch.empty_like(z))
     dev = z.device
     if want_affine and gamma is not None and want_bias:
         # one [3, D] buffer -> the C side finalises all three column sums in a single pass
@@ -384,8 +387,8 @@ def split_rows(t, transpose=False):
     return out
 
 
-def ln_prep(z, gamma, beta, act, eps=LN_EPS):
-    """(mu, rs, h_sx8) with h = act(LayerNorm(z)); z contiguous [R, D], D % 8 == 0."""
+def ln_prep(z, gamma, beta, act, eps=LN_EPS, drop_p=0.0, seed=0):
+    """(mu, rs, h_sx8) with h = drop(act(LayerNorm(z))); z contiguous [R, D], D % 8 == 0."""
     _need_cuda(z, gamma, beta)
     if not z.is_contiguous():
         raise RuntimeError("wf3d.ln_prep: contiguous z required")
@@ -393,7 +396,8 @@ def ln_prep(z, gamma, beta, act, eps=LN_EPS):
     mu = torch.empty(R, dtype=torch.float32, device=z.device)
     rs = torch.empty(R, dtype=torch.float32, device=z.device)
     h = torch.empty_like(z)
-    check(_lib.load().wf3d_ln_prep(_p(z), R, D, _p(gamma), _p(beta), act, eps, _p(mu), _p(rs), _p(h), _stream()), "ln_prep")
+    check(_lib.load().wf3d_ln_prep(_p(z), R, D, _p(gamma), _p(beta), act, eps, float(drop_p), int(seed) & 0xFFFFFFFF,
+                                   _p(mu), _p(rs), _p(h), _stream()), "ln_prep")
     return mu, rs, h
 
 
@@ -417,18 +421,18 @@ def gemm_split(a_s, b_s, bias=None, out=None, accumulate=False):
     return out
 
 
-def split_transpose(t, pro=None):
-    """sx8 [C, R] = split(pro(t)^T) for fp32 t [R, C] (R % 8 == 0); pro = Pro(act, mu, rs, gamma, beta) or None."""
+def split_transpose(t, pro=None, in_sx8=False):
+    """sx8 [C, R] = split(pro(t)^T) for fp32 t [R, C] (R % 8 == 0); pro = Pro(act, mu, rs, gamma, beta) or None.
+    in_sx8=True: t is itself an sx8 matrix and is transposed plane-wise (no prologue)."""
     _need_cuda(t)
     t = _rows2d(t)
     R, C = t.shape
     out = torch.empty(C, R, dtype=torch.float32, device=t.device)
     mu = rs = gamma = beta = None
-    act = ACT_NONE
+    act, drop_p, seed = ACT_NONE, 0.0, 0
     if pro is not None:
-        if pro.drop_p:
-            raise RuntimeError("wf3d.split_transpose: dropout prologue not supported")
-        mu, rs, gamma, beta, act = pro.mu, pro.rs, pro.gamma, pro.beta, pro.act
+        mu, rs, gamma, beta, act, drop_p, seed = pro.mu, pro.rs, pro.gamma, pro.beta, pro.act, pro.drop_p, pro.seed
     check(_lib.load().wf3d_split_transpose(_p(t), R, C, t.stride(0), _p(mu), _p(rs), _p(gamma), _p(beta), act,
-                                           _p(out), _stream()), "split_transpose")
+                                           float(drop_p), int(seed) & 0xFFFFFFFF, 1 if in_sx8 else 0, _p(out),
+                                           _stream()), "split_transpose")
     return out
