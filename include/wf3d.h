@@ -142,10 +142,11 @@ int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, const float* 
                     float* dz, void* dz_sx8, float* dgamma, float* dbeta, float* dbias, void* ws,
                     size_t ws_bytes, void* stream);
 
-/* out[c] = sum_r x[r,c] * (w ? w[r] : 1)   — bias grads of Linears with no LN
- * behind them, and the distance-weight grad of the split edge layer. */
+/* out[c] = sum_r act(x[r,c]) * (w ? w[r] : 1)   — bias grads of Linears with no LN
+ * behind them, the distance-weight grad of the split edge layer, and the weight
+ * grad of a 1-output Linear (edge_mlp.10: dW[c] = sum_r dlogit[r] * gelu(z[r,c])). */
 size_t wf3d_colsum_ws_bytes(int R, int D);
-int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, float* out, void* ws,
+int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, int act, float* out, void* ws,
                 size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -205,6 +205,8 @@ def test_colsum(ops, R, D):
     X, w = rnd(R, D, seed=1), rnd(R, seed=2)
     assert rel(ops.colsum(X), X.double().sum(0)) < TOL_ELT
     assert rel(ops.colsum(X, w), (X.double() * w.double()[:, None]).sum(0)) < TOL_ELT
+    want = (torch.nn.functional.gelu(X.double()) * w.double()[:, None]).sum(0)
+    assert rel(ops.colsum(X, w, ops.ACT_GELU), want) < TOL_ELT
 
 
 @pytest.mark.parametrize("B,N,C", [(3, 37, 16), (2, 1000, 512), (1, 4096, 512), (5, 33, 300)])

@@ -201,13 +201,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 
 // partial column sums: block (bx, by) sums rows [by*rpb, ...) of columns bx*256..
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int R, int D, int ld,
-                                                              const float* __restrict__ w, int rpb,
+                                                              const float* __restrict__ w, int act, int rpb,
                                                               float* __restrict__ part) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= D) return;
     const int r0 = blockIdx.y * rpb, r1 = min(R, r0 + rpb);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + c] * (w ? w[r] : 1.0f);
+    for (int r = r0; r < r1; ++r) s += wf3d_act_rt(act, x[(size_t)r * ld + c]) * (w ? w[r] : 1.0f);
     part[(size_t)blockIdx.y * D + c] = s;
 }
 
@@ -217,7 +217,7 @@ int bwd_nblk(int R) {
 }
 int colsum_nrb(int R) {
     int n = wf3d_cdiv(R, 64);
-    return n > 512 ? 512 : (n < 1 ? 1 : n);
+    return n > 2048 ? 2048 : (n < 1 ? 1 : n);
 }
 
 }  // namespace
@@ -317,9 +317,9 @@ extern "C" size_t wf3d_colsum_ws_bytes(int R, int D) {
     return (size_t)colsum_nrb(R) * D * sizeof(float);
 }
 
-extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, float* out, void* ws,
+extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, int act, float* out, void* ws,
                            size_t ws_bytes, void* stream) {
-    WF3D_CHECK(R >= 0 && D > 0 && ld >= D && out, WF3D_ERR_ARG, "wf3d_colsum: bad args");
+    WF3D_CHECK(R >= 0 && D > 0 && ld >= D && out && act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
     if (R == 0) { hipMemsetAsync(out, 0, D * sizeof(float), st); return WF3D_OK; }
     WF3D_CHECK(x, WF3D_ERR_ARG, "wf3d_colsum: null x");
@@ -327,7 +327,7 @@ extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w,
     WF3D_CHECK(ws && ws_bytes >= (size_t)nrb * D * sizeof(float), WF3D_ERR_WS, "wf3d_colsum: workspace too small");
     const int rpb = wf3d_cdiv(R, nrb);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(wf3d_cdiv(D, 256), nrb), dim3(256), 0, st, x, R, D, ld, w, rpb, part);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(wf3d_cdiv(D, 256), nrb), dim3(256), 0, st, x, R, D, ld, w, act, rpb, part);
     WF3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 64)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
                        (size_t)D, D, out);

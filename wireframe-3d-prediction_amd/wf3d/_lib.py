@@ -54,7 +54,7 @@ SIGNATURES = {
     "wf3d_ln_prep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_u32, c_void_p,
                              c_void_p, c_void_p, c_void_p]),
     "wf3d_colsum_ws_bytes": (c_size_t, [c_int, c_int]),
-    "wf3d_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wf3d_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_point_valid": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_pool4_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "wf3d_pool4_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -309,7 +309,13 @@ class EdgeFn(torch.autograd.Function):
         G = [None] * len(params)
         dlogit = ops.edge_prob_bwd(probs, dprobs.contiguous(), meta)                      # [Re,1]
         G[23] = ops.colsum(dlogit)
-        G[22], dh3 = _lin_bwd(dlogit, z3, M10w, Pro(ACT_GELU))
+        if M10w.shape[0] == 1:
+            # one-output Linear: dW[c] = sum_r dlogit[r]*gelu(z3[r,c]) is a weighted column sum,
+            # d gelu(z3) = dlogit (outer) W — no 128x128 MFMA tile wasted on a 1-wide problem
+            G[22] = ops.colsum(z3, dlogit.view(-1), ACT_GELU).view(1, -1)
+            dh3 = ops.gemm(dlogit, M10w, NN)
+        else:
+            G[22], dh3 = _lin_bwd(dlogit, z3, M10w, Pro(ACT_GELU))
         p2 = Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3])
         p1 = Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])
         tsplit = ctx.split and meta.Re % 8 == 0              # wgrad operands need whole 8-row groups

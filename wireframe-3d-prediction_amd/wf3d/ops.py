@@ -172,7 +172,8 @@ def ln_act_bwd(dh, z, mu, rs, gamma, beta, act, drop_p=0.0, seed=0, want_affine=
     return dz, dgamma, dbeta, dbias
 
 
-def colsum(x, w=None):
+def colsum(x, w=None, act=ACT_NONE):
+    """out[c] = sum_r act(x[r, c]) * w[r]"""
     _need_cuda(x, w)
     x = _rows2d(x)
     R, D = x.shape
@@ -180,7 +181,7 @@ def colsum(x, w=None):
     lib = _lib.load()
     ws = scratch(lib.wf3d_colsum_ws_bytes(R, D), x.device)
     ld = x.stride(0) if R > 1 else D
-    check(lib.wf3d_colsum(_p(x), R, D, ld, _p(w), _p(out), _p(ws), ws.numel() if ws is not None else 0, _stream()),
+    check(lib.wf3d_colsum(_p(x), R, D, ld, _p(w), act, _p(out), _p(ws), ws.numel() if ws is not None else 0, _stream()),
           "colsum")
     return out
 
@@ -319,9 +320,11 @@ def attn_bwd(qkv, dctx, lse, meta, E, heads, drop_p=0.0, seed=0):
 
 
 def _wdelta(W0, H):
-    if tuple(W0.shape) != (H, 2 * H + 7) or not W0.is_contiguous():
-        raise RuntimeError("wf3d: edge_mlp.0.weight must be contiguous [H, 2H+7]")
-    return W0[:, 2 * H + 6], W0.stride(0)
+    """Distance column of edge_mlp.0.weight, gathered once into a contiguous vector (a strided
+    per-lane gather of it inside the pair kernels costs 512 uncoalesced loads per edge row)."""
+    if tuple(W0.shape) != (H, 2 * H + 7):
+        raise RuntimeError("wf3d: edge_mlp.0.weight must be [H, 2H+7]")
+    return W0[:, 2 * H + 6].contiguous(), 1
 
 
 def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS):
