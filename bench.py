@@ -243,7 +243,7 @@ def main():
                 traffic = None
         if split:
             # bf16x3: every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
-            peak, kern = BF16_MFMA_PEAK_TFLOPS, "gemm_kernel<2,2,2,2,NT,split> (128x128x32, 3 x v_mfma_f32_32x32x16_bf16 per k16)"
+            peak, kern = BF16_MFMA_PEAK_TFLOPS, "gemm_split_dma3_kernel (256x128x32 tile, 3-stage LDS-DMA, 3 x v_mfma_f32_32x32x16_bf16 per product)"
             extra = {"executed_mfma_tflops": 3.0 * achieved, "executed_frac": 3.0 * achieved / peak,
                      "note": "achieved = algorithmic 2MNK FLOP / time; the split algorithm issues 3 MFMA FLOP per algorithmic FLOP"}
         else:

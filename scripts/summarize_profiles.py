@@ -67,7 +67,8 @@ def pmc(pattern):
 fetch, write, sq = pmc(f"prof_{tag}_fetch/**/*_counter_collection.csv"), \
     pmc(f"prof_{tag}_write/**/*_counter_collection.csv"), pmc(f"prof_{tag}_sq/**/*_counter_collection.csv")
 
-BIG_US = 800.0          # the encoder's twelve >=137-GFLOP GEMM launches per step all run > 1 ms
+BIG_US = 300.0          # the encoder's twelve >=137-GFLOP GEMM launches per step all run > 0.35 ms
+DOM = os.environ.get("WF3D_DOMINANT", "gemm_split_dma3_kernel")   # dominant kernel (fp32 mode: "gemm_kernel<2, 2, 2, 2")
 
 
 def big(vals):
@@ -85,12 +86,12 @@ for name in sorted(set(fetch) | set(write)):
     if wv:
         e["write_bytes_avg"] = 1024 * sum(v for v, _, _ in wv) / len(wv)
     summary["kernels"][name] = e
-    if name.startswith("gemm_kernel<2, 2, 2, 2"):
+    if name.startswith(DOM):
         gemm_fetch += big(fv)
         gemm_write += big(wv)
 mfma = {}
 for name, ctrs in sq.items():
-    if not name.startswith("gemm_kernel<2, 2, 2, 2"):
+    if not name.startswith(DOM):
         continue
     busy = sum(v for v, d, _ in ctrs.get("SQ_VALU_MFMA_BUSY_CYCLES", []) if d >= BIG_US)
     gui = sum(v for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []) if d >= BIG_US)
@@ -107,7 +108,7 @@ summary["gemm_mfma"] = mfma
 if gemm_fetch and gemm_write:
     rd = 2 * 1024 * sum(gemm_fetch) / len(gemm_fetch)
     wr = 1024 * sum(gemm_write) / len(gemm_write)
-    summary["cfg2"] = {"gemm_launches": len(gemm_fetch), "gemm_read_bytes_per_launch": rd,
+    summary["cfg2"] = {"kernel": DOM, "gemm_launches": len(gemm_fetch), "gemm_read_bytes_per_launch": rd,
                        "gemm_write_bytes_per_launch": wr, "gemm_hbm_bytes_per_launch": rd + wr,
                        "correction": "read = 2 x FETCH_SIZE KiB (gfx950 16-B/lane streams), write = WRITE_SIZE KiB"}
 json.dump(summary, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
@@ -116,13 +117,13 @@ if "cfg2" in summary:
               open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 
 with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary, round {tag} (cfg2: B=32, N=4096, V=64, fp32)\n\n")
+    f.write(f"# rocprofv3 summary, round {tag} (cfg2: B=32, N=4096, V=64; dominant kernel `{DOM}`)\n\n")
     f.write("## kernel-trace --stats (3 timed + 1 warm-up steps)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for n, c, t, a, pc in stats_rows[:30]:
         f.write(f"| `{n}` | {c} | {t:.2f} | {a:.1f} | {pc:.1f} |\n")
     if "cfg2" in summary:
         c = summary["cfg2"]
-        f.write(f"\n## HBM traffic of the dominant kernel (128x128 fp32-MFMA GEMM, launches >= {BIG_US:.0f} us)\n\n")
+        f.write(f"\n## HBM-side traffic of the dominant kernel (`{DOM}`, launches >= {BIG_US:.0f} us)\n\n")
         f.write(f"launches {c['gemm_launches']}: read {c['gemm_read_bytes_per_launch'] / 1e6:.1f} MB + write "
                 f"{c['gemm_write_bytes_per_launch'] / 1e6:.1f} MB = {c['gemm_hbm_bytes_per_launch'] / 1e6:.1f} MB per launch "
                 f"({c['correction']})\n")
