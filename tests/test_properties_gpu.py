@@ -1,0 +1,119 @@
+"""Size-independent properties of the path, checked at BASELINE.json's full cfg2 size
+(B=32, N=4096, V=64) where the CPU oracle would take minutes:
+
+  * permutation invariance over points (PointNet symmetry),
+  * batch independence (a sample's outputs do not depend on its batch mates),
+  * zero-padded points leave the mask-aware global feature unchanged,
+  * backward is linear in the cotangent,
+  * the bf16x3 split-precision mode agrees with the exact-fp32 mode inside the 1e-4 gate,
+  * cfg4 (N=16384) and cfg5 (V=256) shapes run and stay finite.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import helpers as H  # noqa: E402,F401
+
+B, N, V = 32, 4096, 64
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    torch.manual_seed(1234)
+    model = PointCloudToWireframe(8, V).to(dev()).set_dropout(0.0)
+    model.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, N, 8, generator=g).to(dev())
+    counts = torch.randint(2, V + 1, (B,), generator=g).to(dev())
+    out = model(x, counts)
+    return model, x, counts, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+KEYS = ("vertices", "existence_probabilities", "edge_probs", "global_features")
+
+
+def test_point_permutation_invariance(setup):
+    model, x, counts, base = setup
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(dev())
+    out = model(x[:, perm], counts)
+    for k in KEYS:
+        assert rel(out[k].detach(), base[k]) < TOL, k
+    assert out["edge_indices"] == base["edge_indices"]
+
+
+def test_batch_independence(setup):
+    model, x, counts, base = setup
+    for i in (0, 17, 31):
+        out = model(x[i:i + 1], counts[i:i + 1])
+        e = out["edge_probs"].shape[1]
+        assert rel(out["vertices"].detach(), base["vertices"][i:i + 1]) < TOL
+        assert rel(out["edge_probs"].detach(), base["edge_probs"][i:i + 1, :e]) < TOL
+        assert float(base["edge_probs"][i, e:].abs().max()) == 0.0 if e < base["edge_probs"].shape[1] else True
+
+
+def test_zero_padding_leaves_masked_global_feature(setup):
+    model, x, counts, base = setup
+    xp = torch.cat([x, torch.zeros(B, 512, 8, device=dev())], dim=1)
+    g, _pf = model.encoder(xp)
+    assert rel(g.detach(), base["global_features"]) < TOL
+
+
+def test_backward_is_linear_in_the_cotangent(setup):
+    model, x, counts, _ = setup
+    gen = torch.Generator().manual_seed(9)
+
+    def grads(ws):
+        model.zero_grad(set_to_none=True)
+        out = model(x, counts)
+        sum((out[k] * w).sum() for k, w in ws.items()).backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    out = model(x, counts)
+    c1 = {k: torch.randn(out[k].shape, generator=gen).to(dev()) for k in KEYS[:3]}
+    c2 = {k: torch.randn(out[k].shape, generator=gen).to(dev()) for k in KEYS[:3]}
+    g1, g2 = grads(c1), grads(c2)
+    g12 = grads({k: c1[k] + 2.0 * c2[k] for k in c1})
+    for n in g12:
+        want = g1[n].double() + 2.0 * g2[n].double()
+        err = float((g12[n].double() - want).norm() / want.norm().clamp_min(1e-30))
+        assert err < 1e-4, (n, err)
+
+
+def test_split_precision_agrees_with_fp32_at_full_size(setup):
+    from wf3d import config
+    model, x, counts, base = setup
+    assert config.precision() == "bf16x3"
+    config.set_precision("fp32")
+    try:
+        out = model(x, counts)
+    finally:
+        config.set_precision("bf16x3")
+    for k in KEYS:
+        assert rel(base[k], out[k].detach()) < TOL, k
+
+
+@pytest.mark.parametrize("b,n,v", [(8, 16384, 64), (4, 4096, 256)])
+def test_other_baseline_shapes_run(b, n, v):
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    torch.manual_seed(3)
+    model = PointCloudToWireframe(8, v).to(dev())
+    model.train()                                   # dropout p = 0.1 active, as in the reference
+    x = torch.randn(b, n, 8, device=dev())
+    counts = torch.full((b,), v, device=dev())
+    out = model(x, counts)
+    assert out["edge_probs"].shape == (b, v * (v - 1) // 2)
+    (out["edge_probs"].sum() + out["vertices"].sum()).backward()
+    for k in KEYS:
+        assert torch.isfinite(out[k]).all(), k
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
