@@ -525,7 +525,7 @@ extern "C" int wf3d_gemm_split(const void* A_sx8, const void* B_sx8, float* C, c
     WF3D_CHECK(((uintptr_t)A_sx8 % 16 == 0) && ((uintptr_t)B_sx8 % 16 == 0), WF3D_ERR_ARG, "wf3d_gemm_split: operands must be 16-byte aligned");
     {
         // LDS-DMA staged kernel for every shape it supports (WF3D_SPLIT_DMA=0 forces the register-staged one)
-        static const int use_dma = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 3; }();
+        static const int use_dma = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 1; }();
         if (use_dma && wf3d_gemm_split_dma_ok(M, N, K, lda, ldb))
             return wf3d_gemm_split_dma(A_sx8, B_sx8, C, bias, M, N, K, lda, ldb, ldc, accumulate, ws, ws_bytes, stream);
     }

@@ -18,6 +18,10 @@
 
 #include "wf3d_common.h"
 
+#ifndef WF3D_ABLATE
+#define WF3D_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no LDS fragment reads
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -196,7 +200,7 @@ __device__ __forceinline__ void mma12(f32x16 (&acc)[2][2], const Frag& f, bool a
                 constexpr int dummy = 0; (void)dummy;
                 const int piece = P0 + i * 2 + j;
                 __builtin_amdgcn_sched_barrier(0);
-                if (ahead) {
+                if (ahead && WF3D_ABLATE != 1) {
                     if (piece < 4) dma16(asrc[piece < 4 ? piece : 0] + kn, dA + piece * 8 * SBK);
                     else           dma16(bsrc[piece >= 4 ? piece - 4 : 0] + kn, dB + (piece - 4) * 8 * SBK);
                 }
@@ -277,9 +281,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma3_kernel(const SplitPara
         const int kn = (kt + 2) * SBK;
         const float* As = smem + stage * T3_STAGE;
         const float* Bs = As + T3_A;
-        load_frag(X, As, Bs, wm, wn, l31, h, fsw, 0);
+        if (WF3D_ABLATE != 2 || kt == kt0) load_frag(X, As, Bs, wm, wn, l31, h, fsw, 0);
         mma12<0>(acc, X, ahead, asrc, bsrc, kn, dA, dB);
-        load_frag(Y, As, Bs, wm, wn, l31, h, fsw, 1);
+        if (WF3D_ABLATE != 2 || kt == kt0) load_frag(Y, As, Bs, wm, wn, l31, h, fsw, 1);
         mma12<3>(acc, Y, ahead, asrc, bsrc, kn, dA, dB);
         // retire slice kt+1 (all but the 6 youngest DMA pieces), make sure this wave's LDS reads
         // of slice kt are done (lgkmcnt) before anyone may overwrite the stage, then publish.
@@ -316,6 +320,137 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma3_kernel(const SplitPara
     }
 }
 
+// ---------------------------------------------------------------------------
+// 256x256 tile variant: 8 waves (2 x 4), each 128x64 = 4x2 MFMA tiles (128 accumulator
+// registers), TWO LDS stages of 64 KB.  A slice now carries 48 MFMAs per wave (1536 pipe
+// cycles, 3072 per SIMD with two waves), longer than the DMA's issue->landed latency, so
+// a prefetch distance of one slice suffices; per MFMA it needs 25 % fewer global bytes and
+// LDS fragment reads than the 256x128 tile.
+// ---------------------------------------------------------------------------
+constexpr int T4_A = 256 * SBK, T4_STAGE = 2 * T4_A;
+
+__global__ __launch_bounds__(512, 2) void gemm_split_dma256_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * T4_STAGE];      // 131,072 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows wm*128, cols wn*64
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 256;
+    const int ktotal = p.K / SBK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    const float* asrc[4];
+    const float* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = ((lane & 7) ^ ((row >> 1) & 7)) * 4;
+        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
+        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fsw = (l31 >> 1) & 7;
+    if (kt0 < kt1) {
+        float* dA = smem + wave * 4 * 8 * SBK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dma16(asrc[q] + kt0 * SBK, dA + q * 8 * SBK);
+            dma16(bsrc[q] + kt0 * SBK, dA + T4_A + q * 8 * SBK);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool ahead = kt + 1 < kt1;
+        float* dA = smem + (stage ^ 1) * T4_STAGE + wave * 4 * 8 * SBK;
+        float* dB = dA + T4_A;
+        const int kn = (kt + 1) * SBK;
+        const float* As = smem + stage * T4_STAGE;
+        const float* Bs = As + T4_A;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int phi = ((2 * (2 * s2 + h)) ^ fsw) * 4, plo = phi ^ 4;
+            f32x4 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* pr = As + ((wm * 4 + i) * 32 + l31) * SBK;
+                ah[i] = *reinterpret_cast<const f32x4*>(pr + phi);
+                al[i] = *reinterpret_cast<const f32x4*>(pr + plo);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* pr = Bs + ((wn * 2 + j) * 32 + l31) * SBK;
+                bh[j] = *reinterpret_cast<const f32x4*>(pr + phi);
+                bl[j] = *reinterpret_cast<const f32x4*>(pr + plo);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    if (j == 0) {          // one DMA piece after every 6 MFMAs: 4 pieces per k16 step, 8 per slice
+                        const int piece = s2 * 4 + i;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (ahead) {
+                            if (piece < 4) dma16(asrc[piece & 3] + kn, dA + (piece & 3) * 8 * SBK);
+                            else           dma16(bsrc[piece & 3] + kn, dB + (piece & 3) * 8 * SBK);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage ^= 1;
+    }
+
+    const bool split = p.ksplit > 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wn * 2 + j) * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v += bv;
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
     const size_t total = (size_t)p.M * p.N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -329,14 +464,19 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) 
     }
 }
 
-int split_variant() {          // WF3D_SPLIT_DMA: 3 (default) = 256x128 3-stage, 2 = 128x128 2-stage
-    static const int v = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 3; }();
-    return v;
+// Kernel choice.  WF3D_SPLIT_DMA forces one: 2 = 128x128 2-stage, 3 = 256x128 3-stage,
+// 4 = 256x256 2-stage.  Default (unset): 256x256 when the output has >= 512 such tiles (the
+// tall forward / dgrad GEMMs: +4 %), else 256x128 (wgrad: few tiles, long split-K reductions).
+int split_variant(int M, int N) {
+    static const int forced = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 0; }();
+    if (forced >= 2 && forced <= 4) return forced;
+    return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= 512 ? 4 : 3;
 }
 
 void plan(int M, int N, int K, int& ksplit, int& kt_per) {
-    const int bm = split_variant() == 3 ? 256 : 128;
-    const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, 128);
+    const int v = split_variant(M, N);
+    const int bm = v >= 3 ? 256 : 128, bn = v == 4 ? 256 : 128;
+    const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, bn);
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
     if (tiles >= 256 || ktotal < 8) return;
@@ -373,14 +513,16 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     SplitParams p{};
     p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
-    const bool deep = split_variant() == 3;
-    p.nbm = wf3d_cdiv(M, deep ? 256 : 128); p.nbn = wf3d_cdiv(N, 128);
+    const int variant = split_variant(M, N);
+    const bool deep = variant == 3;
+    p.nbm = wf3d_cdiv(M, variant >= 3 ? 256 : 128); p.nbn = wf3d_cdiv(N, variant == 4 ? 256 : 128);
     plan(M, N, K, p.ksplit, p.kt_per_split);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    else if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else      hipLaunchKernelGGL(gemm_split_dma_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libwf3d.so")
+LIB_PATH = os.environ.get("WF3D_LIB", os.path.join(os.path.dirname(_HERE), "libwf3d.so"))   # override: timing-only ablation builds
 
 c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
 c_void_p = ctypes.c_void_p
