@@ -84,12 +84,53 @@ __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __rest
     arg_u_o[o] = au;
 }
 
+// dpf written 16 B per lane: a thread owns 4 channels of one cloud (its 4 pooled cotangents and
+// 2 arg-max indices live in registers) and walks the points of its split; 256/(C/4) points of a
+// split are written per pass, each a contiguous C*4-byte row.
 __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict__ valid, const float* __restrict__ cnt,
                                                          const int32_t* __restrict__ arg_m, const int32_t* __restrict__ arg_u,
                                                          const float* __restrict__ dmmax, const float* __restrict__ dmavg,
                                                          const float* __restrict__ dumean, const float* __restrict__ dumax,
                                                          const float* __restrict__ dpf_direct, int N, int C,
                                                          int npb, float* __restrict__ dpf) {
+    const int b = blockIdx.z;
+    const int tpr = C / 4 < 256 ? C / 4 : 256;             // threads per point row
+    const int rpb = 256 / tpr;                             // point rows per pass
+    const int rsub = threadIdx.x / tpr;
+    const int c = (blockIdx.x * tpr + threadIdx.x % tpr) * 4;
+    if (c >= C || rsub >= rpb) return;
+    const int n0 = blockIdx.y * npb, n1 = min(N, n0 + npb);
+    const size_t o = (size_t)b * C + c;
+    const float inv_cnt = 1.0f / cnt[b], inv_n = 1.0f / (float)N;
+    f32x4 g_avg = {0.f, 0.f, 0.f, 0.f}, g_mean = g_avg, g_mm = g_avg, g_um = g_avg;
+    if (dmavg) g_avg = *reinterpret_cast<const f32x4*>(dmavg + o) * inv_cnt;
+    if (dumean) g_mean = *reinterpret_cast<const f32x4*>(dumean + o) * inv_n;
+    if (dmmax) g_mm = *reinterpret_cast<const f32x4*>(dmmax + o);
+    if (dumax) g_um = *reinterpret_cast<const f32x4*>(dumax + o);
+    int am[4], au[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { am[j] = arg_m[o + j]; au[j] = arg_u[o + j]; }
+    for (int n = n0 + rsub; n < n1; n += rpb) {
+        const size_t idx = ((size_t)b * N + n) * C + c;
+        const float v = valid[(size_t)b * N + n];
+        f32x4 g = g_mean + g_avg * v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (n == am[j]) g[j] += g_mm[j];
+            if (n == au[j]) g[j] += g_um[j];
+        }
+        if (dpf_direct) g += *reinterpret_cast<const f32x4*>(dpf_direct + idx);
+        *reinterpret_cast<f32x4*>(dpf + idx) = g;
+    }
+}
+
+// scalar fallback for channel counts that are not a multiple of 4
+__global__ __launch_bounds__(256) void pool4_bwd_scalar_kernel(const float* __restrict__ valid, const float* __restrict__ cnt,
+                                                                const int32_t* __restrict__ arg_m, const int32_t* __restrict__ arg_u,
+                                                                const float* __restrict__ dmmax, const float* __restrict__ dmavg,
+                                                                const float* __restrict__ dumean, const float* __restrict__ dumax,
+                                                                const float* __restrict__ dpf_direct, int N, int C,
+                                                                int npb, float* __restrict__ dpf) {
     const int b = blockIdx.z;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -164,10 +205,21 @@ extern "C" int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_
                               const float* dpf_direct, int B, int N, int C, float* dpf, void* stream) {
     WF3D_CHECK(B > 0 && N > 0 && C > 0 && B <= 65535, WF3D_ERR_ARG, "wf3d_pool4_bwd: bad dims");
     WF3D_CHECK(valid && cnt && arg_m && arg_u && dpf, WF3D_ERR_ARG, "wf3d_pool4_bwd: null pointer");
-    const int ns = pool_nsplit(B, N, C);
-    const int npb = wf3d_cdiv(N, ns);
-    hipLaunchKernelGGL(pool4_bwd_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, (hipStream_t)stream, valid, cnt,
-                       arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+    const bool vec = C % 4 == 0 && ((uintptr_t)dpf % 16 == 0) && (!dpf_direct || (uintptr_t)dpf_direct % 16 == 0) &&
+                     (C / 4 >= 256 || 256 % (C / 4) == 0);
+    if (vec) {
+        int ns = 4096 / (B * wf3d_cdiv(C / 4, 256));
+        const int cap = wf3d_cdiv(N, 16);
+        ns = ns > cap ? cap : (ns < 1 ? 1 : ns);
+        const int npb = wf3d_cdiv(N, ns);
+        hipLaunchKernelGGL(pool4_bwd_kernel, dim3(wf3d_cdiv(C / 4, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
+                           valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+    } else {
+        const int ns = pool_nsplit(B, N, C);
+        const int npb = wf3d_cdiv(N, ns);
+        hipLaunchKernelGGL(pool4_bwd_scalar_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
+                           valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+    }
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

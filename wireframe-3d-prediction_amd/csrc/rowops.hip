@@ -75,39 +75,50 @@ __global__ __launch_bounds__(256) void ln_act_apply_kernel(const float* __restri
 // z and dh are read from HBM exactly once; column partials live in registers
 // across the block's rows and are combined through LDS, then per-block
 // partials [nblk][3][D] are summed by colsum_finalize (deterministic, no atomics).
-template <int NS>
+// A row is shared by WPR waves of the workgroup (D/WPR columns each, NS float4 slots per lane)
+// so that the per-lane state stays small (<= ~100 VGPRs -> >= 4 waves per SIMD): with one wave
+// per 2048-wide row the kernel sat at 256 VGPRs / 1 wave per SIMD and 2.3 TB/s.  Row sums cross
+// the waves through a double-buffered LDS slot and one barrier per row group.
+template <int NS, int WPR>
 __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z,
                                                           int R, int D, const float* __restrict__ mu,
                                                           const float* __restrict__ rs, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, uint32_t seed,
                                                           uint32_t thresh, float scale, float* __restrict__ dz,
                                                           float* __restrict__ dz_sx8, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [3][D] block combine
+    constexpr int RPI = 4 / WPR;                       // rows per workgroup iteration
+    __shared__ float xsum[2][4][2];                    // [parity][wave][s1, s2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wslice = wave % WPR, wrow = wave / WPR;
+    const int Dw = (D / 4 + WPR - 1) / WPR * 4;        // columns per wave slice (multiple of 4)
+    const int cbeg = wslice * Dw, cend = min(D, cbeg + Dw);
     const bool has_ln = mu != nullptr;
     f32x4 gam[NS], bet[NS];
     f32x4 a_dg[NS], a_db[NS], a_dbias[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int c = lane * 4 + 256 * i;
+        const int c = cbeg + lane * 4 + 256 * i;
         gam[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
         bet[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (gamma && c < D) {
+        if (gamma && c < cend) {
             gam[i] = *reinterpret_cast<const f32x4*>(gamma + c);
             bet[i] = *reinterpret_cast<const f32x4*>(beta + c);
         }
         a_dg[i] = a_db[i] = a_dbias[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const float invD = 1.0f / (float)D;
-    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
-        const float m = has_ln ? mu[row] : 0.f, r = has_ln ? rs[row] : 1.f;
+    const int iters = (R + gridDim.x * RPI - 1) / (gridDim.x * RPI);
+    for (int it = 0; it < iters; ++it) {
+        const int row = (it * gridDim.x + blockIdx.x) * RPI + wrow;
+        const bool live = row < R;
+        const float m = (has_ln && live) ? mu[row] : 0.f, r = (has_ln && live) ? rs[row] : 1.f;
         f32x4 xh[NS], gg[NS];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int c = lane * 4 + 256 * i;
+            const int c = cbeg + lane * 4 + 256 * i;
             xh[i] = gg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c < D) {
+            if (live && c < cend) {
                 const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
                 const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c);
 #pragma unroll
@@ -124,11 +135,22 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
             }
         }
         float c1 = 0.f, c2 = 0.f;
-        if (has_ln) { c1 = wf3d_wave_sum(s1) * invD; c2 = wf3d_wave_sum(s2) * invD; }
+        if (has_ln) {
+            s1 = wf3d_wave_sum(s1); s2 = wf3d_wave_sum(s2);
+            if (WPR > 1) {
+                const int par = it & 1;
+                if (lane == 0) { xsum[par][wave][0] = s1; xsum[par][wave][1] = s2; }
+                __syncthreads();
+                s1 = 0.f; s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WPR; ++w) { s1 += xsum[par][wrow * WPR + w][0]; s2 += xsum[par][wrow * WPR + w][1]; }
+            }
+            c1 = s1 * invD; c2 = s2 * invD;
+        }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < D) {
+            const int c = cbeg + lane * 4 + 256 * i;
+            if (live && c < cend) {
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -157,14 +179,16 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
             }
         }
     }
-    // block combine of the 4 waves' column partials, then one partial row per block
+    // column partials: waves of the same slice (different rows) combine through LDS, then one
+    // partial row [3][D] per workgroup
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [3][D]
     for (int k = 0; k < 3; ++k) {
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
+        for (int w = 0; w < RPI; ++w) {
+            if (wrow == w) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    const int c = lane * 4 + 256 * i;
-                    if (c < D) {
+                    const int c = cbeg + lane * 4 + 256 * i;
+                    if (c < cend) {
                         f32x4 v = k == 0 ? a_dg[i] : (k == 1 ? a_db[i] : a_dbias[i]);
                         f32x4* dst = reinterpret_cast<f32x4*>(red + k * D + c);
                         if (w) v += *dst;
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 int bwd_nblk(int R) {
     int n = wf3d_cdiv(R, 4);
-    return n > 512 ? 512 : (n < 1 ? 1 : n);
+    return n > 1024 ? 1024 : (n < 1 ? 1 : n);
 }
 int colsum_nrb(int R) {
     int n = wf3d_cdiv(R, 64);
@@ -284,15 +308,15 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
     const float scale = 1.0f / (1.0f - drop_p);
     float* part = (float*)ws;
     const size_t lds = (size_t)3 * D * sizeof(float);
-    const int ns = wf3d_cdiv(D, 256);
-#define WF3D_BWD(NS_)                                                                                              \
-    hipLaunchKernelGGL((ln_act_bwd_kernel<NS_>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
-                       act, drop_seed, thresh, scale, dz, (float*)dz_sx8, part)
-    if (ns <= 1) WF3D_BWD(1);
-    else if (ns <= 2) WF3D_BWD(2);
-    else if (ns <= 4) WF3D_BWD(4);
-    else if (ns <= 8) WF3D_BWD(8);
-    else WF3D_BWD(16);
+    // waves per row: keep <= 2 float4 slots per lane (NS) wherever possible
+    const int wpr = D > 512 ? 4 : (D > 256 ? 2 : 1);
+    const int ns = wf3d_cdiv(wf3d_cdiv(D / 4, wpr) * 4, 256);
+#define WF3D_BWD(NS_, WPR_)                                                                                       \
+    hipLaunchKernelGGL((ln_act_bwd_kernel<NS_, WPR_>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, \
+                       beta, act, drop_seed, thresh, scale, dz, (float*)dz_sx8, part)
+    if (wpr == 4) { if (ns <= 1) WF3D_BWD(1, 4); else if (ns <= 2) WF3D_BWD(2, 4); else WF3D_BWD(4, 4); }
+    else if (wpr == 2) WF3D_BWD(1, 2);
+    else WF3D_BWD(1, 1);
 #undef WF3D_BWD
     WF3D_LAUNCH_CHECK();
     float* outs[3] = {dgamma, dbeta, dbias};
