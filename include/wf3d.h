@@ -100,6 +100,13 @@ int wf3d_gemm(const wf3d_gemm_t* desc, void* stream);
 size_t wf3d_gemm_split_ws_bytes(int M, int N, int K);
 int wf3d_gemm_split(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N, int K,
                     int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* C[Mo,No] (+)= A^T·B with A = sx8[K,Mo], B = sx8[K,No]: the Linear wgrad dW = dY^T·X on the
+ * operands exactly as backward/forward leave them (no transposed copies; fragments are gathered
+ * with ds_read_b64_tr_b16).  Supported when wf3d_gemm_split_tn_ok() (Mo % 256, No % 128, K % 32). */
+int wf3d_gemm_split_tn_ok(int Mo, int No, int K, int lda, int ldb);
+size_t wf3d_gemm_split_tn_ws_bytes(int Mo, int No, int K);
+int wf3d_gemm_split_tn(const void* A_sx8, const void* B_sx8, float* C, int Mo, int No, int K, int lda, int ldb,
+                       int ldc, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* out_sx8[r, c] = split(in[r*row_stride + c*col_stride])  (col_stride 1: convert;
  * row_stride 1: transpose-convert, used for W^T) */
 int wf3d_split_rows(const float* in, long row_stride, long col_stride, int R, int C, void* out_sx8, void* stream);

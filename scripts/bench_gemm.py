@@ -29,6 +29,10 @@ for K, N in layers:
     Xs, Ws, Gs, WTs = ops.split_rows(X), ops.split_rows(W), ops.split_rows(G), ops.split_rows(W, transpose=True)
     cases.append((f"SPLIT NT K={K} N={N}", lambda Xs=Xs, Ws=Ws, o=o_nt: ops.gemm_split(Xs, Ws, out=o), fl))
     cases.append((f"SPLIT dgrad K={N} N={K}", lambda Gs=Gs, WTs=WTs, o=o_nn: ops.gemm_split(Gs, WTs, out=o), fl))
+    Gts, Xts = ops.split_transpose(Gs, in_sx8=True), ops.split_transpose(Xs, in_sx8=True)
+    cases.append((f"SPLIT wgrad(NT on transposes) {N}x{K}", lambda a=Gts, b=Xts, o=o_tn: ops.gemm_split(a, b, out=o), fl))
+    cases.append((f"SPLIT wgrad(TN tr-read) {N}x{K}", lambda a=Gs, b=Xs, o=o_tn: ops.gemm_split_tn(a, b, out=o), fl))
+    cases.append((f"SPLIT transposes for wgrad {N}x{K}", lambda a=Gs, b=Xs: (ops.split_transpose(a, in_sx8=True), ops.split_transpose(b, in_sx8=True)), fl))
     cases.append((f"TN+pro K={M} out={N}x{K}", lambda G=G, X=X, pro=pro, o=o_tn: ops.gemm(G, X, ops.TN, pro=pro, out=o), fl))
 if os.environ.get("ONLY"):
     cases = [c for c in cases if os.environ["ONLY"] in c[0]]

@@ -357,3 +357,24 @@ def test_split_transpose_and_wgrad_form(ops, act, R, C):
     G = rnd(R, N, seed=5)
     dW = ops.gemm_split(ops.split_transpose(G), ops.split_transpose(Z, pro))
     assert rel(dW, G.double().cpu().T @ want) < TOL_SPLIT
+
+
+@pytest.mark.parametrize("K,Mo,No", [(32, 256, 128), (64, 256, 128), (4096, 512, 256), (1024, 256, 384), (131072, 256, 128)])
+def test_gemm_split_tn_matches_transposed_nt_path(ops, K, Mo, No):
+    """wgrad on reduction-major operands (transposing LDS reads) == the NT kernel on materialised
+    transposes, and == fp64 within the split tolerance."""
+    A, B = rnd(K, Mo, seed=1), rnd(K, No, seed=2)
+    As, Bs = ops.split_rows(A), ops.split_rows(B)
+    assert ops.gemm_split_tn_ok(As, Bs)
+    got = ops.gemm_split_tn(As, Bs)
+    want = ref64(lambda a, b: a.T @ b, A, B)
+    assert rel(got, want) < TOL_SPLIT
+    via_t = ops.gemm_split(ops.split_transpose(As, in_sx8=True), ops.split_transpose(Bs, in_sx8=True))
+    assert rel(got, via_t) < 5e-6           # same products, different tile / split-K summation order
+    # asymmetric integer data catches any lane / row mix-up of the transposing reads exactly
+    Ai = (torch.arange(K * Mo, device=dev()).reshape(K, Mo) % 13 - 6).float()
+    Bi = (torch.arange(K * No, device=dev()).reshape(K, No) % 7 - 3).float()
+    if K <= 4096:
+        gi = ops.gemm_split_tn(ops.split_rows(Ai), ops.split_rows(Bi))
+        assert torch.equal(gi.cpu().double(), Ai.double().cpu().T @ Bi.double().cpu())
+    assert not ops.gemm_split_tn_ok(ops.split_rows(rnd(64, 136, seed=3)), Bs[:64])

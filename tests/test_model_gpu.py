@@ -264,21 +264,26 @@ def test_split_mode_is_active_and_close_to_fp32():
     from wf3d import config, ops
     gold, model, x, arrs, counts, V, seed, train = build_full("cfg1")
     xd, cd = torch.from_numpy(x).to(dev()), counts.to(dev())
-    calls = {"n": 0}
-    orig = ops.gemm_split
+    calls = {"nt": 0, "tn": 0}
+    orig, orig_tn = ops.gemm_split, ops.gemm_split_tn
 
     def spy(*a, **k):
-        calls["n"] += 1
+        calls["nt"] += 1
         return orig(*a, **k)
 
-    ops.gemm_split = spy
+    def spy_tn(*a, **k):
+        calls["tn"] += 1
+        return orig_tn(*a, **k)
+
+    ops.gemm_split, ops.gemm_split_tn = spy, spy_tn
     try:
         assert config.precision() == "bf16x3"
         out_s = model(xd, cd)
         sum(out_s[k].sum() for k in ("vertices", "edge_probs")).backward()
     finally:
-        ops.gemm_split = orig
-    assert calls["n"] == 4 + 4 + 4          # 4 forward, 4 dgrad, 4 wgrad split GEMMs (layers 2..5)
+        ops.gemm_split, ops.gemm_split_tn = orig, orig_tn
+    # layers 2..5 of the per-point MLP: 4 forward + 4 dgrad (NT form) and 4 wgrad (TN form) split GEMMs
+    assert calls == {"nt": 8, "tn": 4}
     config.set_precision("fp32")
     try:
         out_f = model(xd, cd)

@@ -321,6 +321,179 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma3_kernel(const SplitPara
 }
 
 // ---------------------------------------------------------------------------
+// TN form (wgrad): C[Mo,No] = A^T·B with A = sx8[K,Mo], B = sx8[K,No] — both operands
+// reduction-major exactly as the forward/backward passes leave them (h and dz), so no
+// transposed copies are materialised.  Tiles [32 k-rows][cols] are DMA'd row by row and
+// the MFMA fragments (8 consecutive k of one column) are gathered by the hardware
+// transposing read ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block of
+// 16-bit elements and each lane receives one column of it.  An sx8 row keeps the 8 high
+// (or low) parts of 8 consecutive columns in one 16-B chunk, which is exactly the 4-column
+// 8-B pieces that instruction addresses.  Swizzle: chunk' = chunk ^ ((k&1) | (k&2)<<2)
+// puts the 4 rows x 4 chunks a half-wave reads on 16 distinct 16-B slots (conflict-free).
+// Same pipeline as gemm_split_dma3_kernel (256x128 tile, 8 waves, 3 stages, counted vmcnt).
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 tr_frag(const char* base, int off, int row_bytes) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off + 4 * row_bytes));
+    return __builtin_bit_cast(f32x4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int P0>
+__device__ __forceinline__ void mma12_tn(f32x16 (&acc)[2][2], const Frag& f, bool ahead, const float* const (&asrc)[4],
+                                         const float* const (&bsrc)[2], size_t ka, size_t kb, float* dA, float* dB) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bl[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.ah[i]), __builtin_bit_cast(bf16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+            if (i * 2 + j < 3) {
+                const int piece = P0 + i * 2 + j;
+                __builtin_amdgcn_sched_barrier(0);
+                if (ahead) {
+                    if (piece < 4) dma16(asrc[piece < 4 ? piece : 0] + ka, dA + piece * 256);
+                    else           dma16(bsrc[piece >= 4 ? piece - 4 : 0] + kb, dB + (piece - 4) * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_split_tn_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * T3_STAGE];      // A slice 32x256, B slice 32x128 floats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 128;      // p.M = Mo, p.N = No (full tiles only)
+    const int ktotal = p.K / SBK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    // DMA: A piece = one k-row of the tile (1 KB, 64 chunks); B piece = two k-rows (2 x 512 B)
+    const float* asrc[4];
+    const float* bsrc[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kr = wave * 4 + q;
+        const int f = (kr & 1) | ((kr & 2) << 2);
+        asrc[q] = p.A + (size_t)kr * p.lda + m0 + (lane ^ f) * 4;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int kr = (wave * 2 + q) * 2 + (lane >> 5);
+        const int f = (kr & 1) | ((kr & 2) << 2);
+        bsrc[q] = p.B + (size_t)kr * p.ldb + n0 + ((lane & 31) ^ f) * 4;
+    }
+    const size_t astep = (size_t)SBK * p.lda, bstep = (size_t)SBK * p.ldb;   // floats per 32-row slice
+
+    // fragment byte offsets inside a stage (transposing reads): lane = 16*gi + 4*q + pp
+    const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int fq = (tq & 1) | ((tq & 2) << 2);
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c0 = (wm * 2 + i) * 32 + 16 * (gi & 1) + 4 * tp;                 // column inside the 256-wide A tile
+        aoff[i] = (8 * (gi >> 1) + tq) * 1024 + (((2 * (c0 >> 3)) ^ fq) * 16) + (c0 & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c0 = (wn * 2 + j) * 32 + 16 * (gi & 1) + 4 * tp;                 // column inside the 128-wide B tile
+        boff[j] = (8 * (gi >> 1) + tq) * 512 + (((2 * (c0 >> 3)) ^ fq) * 16) + (c0 & 7) * 2;
+    }
+    auto load_frag_tn = [&](Frag& f, const char* As, const char* Bs, int s2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = tr_frag(As, aoff[i] + s2 * 16 * 1024, 1024);
+            f.al[i] = tr_frag(As, (aoff[i] ^ 16) + s2 * 16 * 1024, 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.bh[j] = tr_frag(Bs, boff[j] + s2 * 16 * 512, 512);
+            f.bl[j] = tr_frag(Bs, (boff[j] ^ 16) + s2 * 16 * 512, 512);
+        }
+    };
+    auto issue = [&](int kt, int stage) {
+        float* As = smem + stage * T3_STAGE + wave * 4 * 256;
+        float* Bs = smem + stage * T3_STAGE + T3_A + wave * 2 * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16(asrc[q] + kt * astep, As + q * 256);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16(bsrc[q] + kt * bstep, Bs + q * 256);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (kt0 < kt1) issue(kt0, 0);
+    if (kt0 + 1 < kt1) {
+        issue(kt0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    Frag X, Y;
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool ahead = kt + 2 < kt1;
+        const int nstage = stage == 0 ? 2 : stage - 1;
+        float* dA = smem + nstage * T3_STAGE + wave * 4 * 256;
+        float* dB = smem + nstage * T3_STAGE + T3_A + wave * 2 * 256;
+        const size_t ka = (size_t)(kt + 2) * astep, kb = (size_t)(kt + 2) * bstep;
+        const char* As = reinterpret_cast<const char*>(smem + stage * T3_STAGE);
+        const char* Bs = As + T3_A * 4;
+        load_frag_tn(X, As, Bs, 0);
+        mma12_tn<0>(acc, X, ahead, asrc, bsrc, ka, kb, dA, dB);
+        load_frag_tn(Y, As, Bs, 1);
+        mma12_tn<3>(acc, Y, ahead, asrc, bsrc, ka, kb, dA, dB);
+        if (ahead) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    const bool split = p.ksplit > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wn * 2 + j) * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 256x256 tile variant: 8 waves (2 x 4), each 128x64 = 4x2 MFMA tiles (128 accumulator
 // registers), TWO LDS stages of 64 KB.  A slice now carries 48 MFMAs per wave (1536 pipe
 // cycles, 3072 per SIMD with two waves), longer than the DMA's issue->landed latency, so
@@ -527,6 +700,61 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const size_t total = (size_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        WF3D_LAUNCH_CHECK();
+    }
+    return WF3D_OK;
+}
+
+// C[Mo,No] (+)= A^T·B, A = sx8[K,Mo], B = sx8[K,No]  (Linear wgrad: A = dY, B = X, both as stored)
+extern "C" int wf3d_gemm_split_tn_ok(int Mo, int No, int K, int lda, int ldb) {
+    return Mo > 0 && No > 0 && K >= SBK && Mo % 256 == 0 && No % 128 == 0 && K % SBK == 0 && lda % 4 == 0 && ldb % 4 == 0;
+}
+
+namespace {
+void plan_tn(int Mo, int No, int K, int& ksplit, int& kt_per) {
+    const long tiles = (long)(Mo / 256) * (No / 128);
+    const int ktotal = K / SBK;
+    ksplit = 1; kt_per = ktotal;
+    if (tiles >= 256 || ktotal < 8) return;
+    int want = (int)((512 + tiles - 1) / tiles);
+    int ks = want < ktotal / 4 ? want : ktotal / 4;
+    if (ks > 64) ks = 64;
+    if (ks < 2) return;
+    kt_per = wf3d_cdiv(ktotal, ks);
+    ksplit = wf3d_cdiv(ktotal, kt_per);
+}
+}  // namespace
+
+extern "C" size_t wf3d_gemm_split_tn_ws_bytes(int Mo, int No, int K) {
+    if (Mo <= 0 || No <= 0 || K <= 0) return 0;
+    int ks, per;
+    plan_tn(Mo, No, K, ks, per);
+    return ks > 1 ? (size_t)ks * Mo * No * sizeof(float) : 0;
+}
+
+extern "C" int wf3d_gemm_split_tn(const void* A_sx8, const void* B_sx8, float* C, int Mo, int No, int K, int lda,
+                                  int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    WF3D_CHECK(wf3d_gemm_split_tn_ok(Mo, No, K, lda, ldb), WF3D_ERR_UNSUPPORTED,
+               "wf3d_gemm_split_tn: needs Mo %% 256 == 0, No %% 128 == 0, K %% 32 == 0 (Mo=%d No=%d K=%d)", Mo, No, K);
+    WF3D_CHECK(A_sx8 && B_sx8 && C, WF3D_ERR_ARG, "wf3d_gemm_split_tn: null operand");
+    WF3D_CHECK(lda >= Mo && ldb >= No && ldc >= No, WF3D_ERR_ARG, "wf3d_gemm_split_tn: leading dimension too small");
+    WF3D_CHECK(((uintptr_t)A_sx8 % 16 == 0) && ((uintptr_t)B_sx8 % 16 == 0), WF3D_ERR_ARG, "wf3d_gemm_split_tn: misaligned operand");
+    SplitParams p{};
+    p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = nullptr;
+    p.M = Mo; p.N = No; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
+    p.nbm = Mo / 256; p.nbn = No / 128;
+    plan_tn(Mo, No, K, p.ksplit, p.kt_per_split);
+    const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * Mo * No * sizeof(float) : 0;
+    if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
+    p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_split_tn_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    WF3D_LAUNCH_CHECK();
+    if (p.ksplit > 1) {
+        const size_t total = (size_t)Mo * No;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);

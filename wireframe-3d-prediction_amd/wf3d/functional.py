@@ -59,7 +59,7 @@ class EncoderFn(torch.autograd.Function):
             x2 = x2.contiguous()
         split = precision == "bf16x3"
         valid = ops.point_valid(x2)
-        zs, stats = [], []
+        zs, stats, hs = [], [], []                 # hs[i] = sx8 operand consumed by Linear i+1 (kept for its wgrad)
         a, a_s, pro = x2, None, None
         for i in range(n_hidden + 1):
             last = i == n_hidden
@@ -77,6 +77,7 @@ class EncoderFn(torch.autograd.Function):
                 mu, rs, a_s = ops.ln_prep(z, g, be, ACT_RELU)
             else:
                 mu, rs = ops.row_stats(z)
+            hs.append(a_s)
             zs.append(z)
             stats.append((mu, rs))
             pro = Pro(ACT_RELU, mu, rs, g, be)
@@ -93,7 +94,7 @@ class EncoderFn(torch.autograd.Function):
         gl = ops.gemm(f3, F[8], NT, bias=F[9], pro=Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
         ctx.n_hidden, ctx.dims, ctx.split = n_hidden, (B, N, C), split
         ctx.params = params
-        ctx.saved = (x2, valid, zs, stats, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt)
+        ctx.saved = (x2, valid, zs, stats, hs, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt)
         pf3 = pf.view(B, N, C)
         return gl, pf3, umean, umax
 
@@ -102,7 +103,7 @@ class EncoderFn(torch.autograd.Function):
         nh, (B, N, C), split = ctx.n_hidden, ctx.dims, ctx.split
         M = B * N
         params = ctx.params
-        x2, valid, zs, stats, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt = ctx.saved
+        x2, valid, zs, stats, hs, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt = ctx.saved
         F = params[4 * nh + 2:]
         grads = [None] * len(params)
         gF = 4 * nh + 2
@@ -139,7 +140,8 @@ class EncoderFn(torch.autograd.Function):
                 want_s = i > 0 and _split_ok(M, W.shape[0], split)
                 dz_s = torch.empty_like(dh) if want_s else None
                 # with both consumers (dgrad, wgrad) on the split path the fp32 dz is never needed
-                all_split = want_s and _split_ok(M, W.shape[1], split) and M % 8 == 0
+                tn_ok = want_s and hs[i - 1] is not None and ops.gemm_split_tn_ok(dh, hs[i - 1])
+                all_split = want_s and (tn_ok or (_split_ok(M, W.shape[1], split) and M % 8 == 0))
                 dz, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1] = ops.ln_act_bwd(
                     dh, zs[i], mu, rs, g, be, ACT_RELU, inplace=True, dz_split=dz_s, want_dz=not all_split)
             else:
@@ -152,8 +154,13 @@ class EncoderFn(torch.autograd.Function):
             else:
                 a_prev, pro_prev = x2, None
             K = W.shape[1]
-            if i > 0 and dz_s is not None and _split_ok(M, K, split) and M % 8 == 0:
-                # wgrad dW = dz^T · h_prev as an NT-form split GEMM over the point index
+            h_prev_s = hs[i - 1] if i > 0 else None
+            if i > 0 and dz_s is not None and h_prev_s is not None and ops.gemm_split_tn_ok(dz_s, h_prev_s):
+                # wgrad dW = dz^T · h_prev straight from the reduction-major sx8 operands (transposing LDS reads)
+                grads[4 * i] = ops.gemm_split_tn(dz_s, h_prev_s)
+                hs[i - 1] = None
+            elif i > 0 and dz_s is not None and _split_ok(M, K, split) and M % 8 == 0:
+                # same through materialised transposes (shapes the TN kernel does not tile)
                 grads[4 * i] = ops.gemm_split(ops.split_transpose(dz_s, in_sx8=True), ops.split_transpose(a_prev, pro_prev))
             else:
                 grads[4 * i] = ops.gemm(dz, a_prev, TN, pro=pro_prev)
@@ -286,15 +293,15 @@ class EdgeFn(torch.autograd.Function):
             mu2, rs2, h2 = ops.ln_prep(z2, M5g, M5b, ACT_GELU, drop_p=p2_, seed=sd[3])
             s2 = (mu2, rs2)
             z3 = ops.gemm_split(h2, ops.split_rows(M8w), bias=M8b)
-            del h1, h2
         else:
+            h1 = h2 = None
             z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])); s2 = ops.row_stats(z2)
             z3 = ops.gemm(z2, M8w, NT, bias=M8b, pro=Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3]))
         logit = ops.gemm(z3, M10w, NT, bias=M10b, pro=Pro(ACT_GELU))
         probs = ops.edge_prob_fwd(logit, meta)
         ctx.params, ctx.cfg = params, (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
         ctx.split = split
-        ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3)
+        ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2)
         ctx.save_for_backward(probs)
         return probs
 
@@ -304,7 +311,7 @@ class EdgeFn(torch.autograd.Function):
         (P0w, P0b, P1g, P1b, P3w, P3b, P4g, P4b, Aw, Ab, Ow, Ob,
          M0w, M0b, M1g, M1b, M4w, M4b, M5g, M5b, M8w, M8b, M10w, M10b) = params
         B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta = ctx.cfg
-        cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3 = ctx.saved
+        cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2 = ctx.saved
         (probs,) = ctx.saved_tensors
         G = [None] * len(params)
         dlogit = ops.edge_prob_bwd(probs, dprobs.contiguous(), meta)                      # [Re,1]
@@ -318,20 +325,28 @@ class EdgeFn(torch.autograd.Function):
             G[22], dh3 = _lin_bwd(dlogit, z3, M10w, Pro(ACT_GELU))
         p2 = Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3])
         p1 = Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])
-        tsplit = ctx.split and meta.Re % 8 == 0              # wgrad operands need whole 8-row groups
+        tsplit = ctx.split and meta.Re % 8 == 0              # (transposed) wgrad operands need whole 8-row groups
         if ctx.split:
             dz3_s = torch.empty_like(dh3)
+            tn3 = ops.gemm_split_tn_ok(dh3, h2)             # dz3_s has dh3's shape
             dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True,
-                                              dz_split=dz3_s, want_dz=not tsplit)
-            G[20] = (ops.gemm_split(ops.split_transpose(dz3_s, in_sx8=True), ops.split_transpose(z2, p2)) if tsplit
-                     else ops.gemm(dz3, z2, TN, pro=p2))
+                                              dz_split=dz3_s, want_dz=not (tsplit or tn3))
+            if ops.gemm_split_tn_ok(dz3_s, h2):
+                G[20] = ops.gemm_split_tn(dz3_s, h2)
+            else:
+                G[20] = (ops.gemm_split(ops.split_transpose(dz3_s, in_sx8=True), ops.split_transpose(z2, p2)) if tsplit
+                         else ops.gemm(dz3, z2, TN, pro=p2))
             dh2 = ops.gemm_split(dz3_s, ops.split_rows(M8w, transpose=True))
             del dz3, dz3_s
             dz2_s = torch.empty_like(dh2)
+            tn2 = ops.gemm_split_tn_ok(dh2, h1)
             dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3],
-                                                      inplace=True, dz_split=dz2_s, want_dz=not tsplit)
-            G[16] = (ops.gemm_split(ops.split_transpose(dz2_s, in_sx8=True), ops.split_transpose(pre, p1)) if tsplit
-                     else ops.gemm(dz2, pre, TN, pro=p1))
+                                                      inplace=True, dz_split=dz2_s, want_dz=not (tsplit or tn2))
+            if ops.gemm_split_tn_ok(dz2_s, h1):
+                G[16] = ops.gemm_split_tn(dz2_s, h1)
+            else:
+                G[16] = (ops.gemm_split(ops.split_transpose(dz2_s, in_sx8=True), ops.split_transpose(pre, p1)) if tsplit
+                         else ops.gemm(dz2, pre, TN, pro=p1))
             dh1 = ops.gemm_split(dz2_s, ops.split_rows(M4w, transpose=True))
             del dz2, dz2_s
         else:

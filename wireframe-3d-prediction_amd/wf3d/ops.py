@@ -439,3 +439,27 @@ def split_transpose(t, pro=None, in_sx8=False):
                                            float(drop_p), int(seed) & 0xFFFFFFFF, 1 if in_sx8 else 0, _p(out),
                                            _stream()), "split_transpose")
     return out
+
+
+def gemm_split_tn_ok(a_s, b_s):
+    return bool(_lib.load().wf3d_gemm_split_tn_ok(a_s.shape[1], b_s.shape[1], a_s.shape[0], a_s.stride(0), b_s.stride(0)))
+
+
+def gemm_split_tn(a_s, b_s, out=None, accumulate=False):
+    """C[Mo,No] = A^T·B with A = sx8[K,Mo], B = sx8[K,No] (wgrad on operands as stored)."""
+    _need_cuda(a_s, b_s, out)
+    a_s, b_s = _rows2d(a_s), _rows2d(b_s)
+    K, Mo = a_s.shape
+    K2, No = b_s.shape
+    if K != K2:
+        raise RuntimeError("wf3d.gemm_split_tn: reduction dims differ")
+    if out is None:
+        if accumulate:
+            raise RuntimeError("wf3d.gemm_split_tn: accumulate needs `out`")
+        out = torch.empty(Mo, No, dtype=torch.float32, device=a_s.device)
+    lib = _lib.load()
+    ws = scratch(lib.wf3d_gemm_split_tn_ws_bytes(Mo, No, K), a_s.device)
+    check(lib.wf3d_gemm_split_tn(_p(a_s), _p(b_s), _p(out), Mo, No, K, a_s.stride(0), b_s.stride(0), out.stride(0),
+                                 1 if accumulate else 0, _p(ws), ws.numel() if ws is not None else 0, _stream()),
+          "gemm_split_tn")
+    return out
