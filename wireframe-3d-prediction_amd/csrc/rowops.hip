@@ -202,25 +202,32 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     for (int idx = threadIdx.x; idx < 3 * D; idx += 256) part[(size_t)blockIdx.x * 3 * D + idx] = red[idx];
 }
 
-// out[c] = sum_b part[b*stride + c].  64 columns per workgroup, the partial rows
-// split 4 ways over the waves (coalesced 256-B reads), combined through LDS.
+// out[c] = sum_b part[b*stride + c].  32 columns per workgroup, the partial rows split 8 ways
+// over the thread groups (coalesced 128-B reads, 4 loads in flight per thread), combined through LDS.
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, size_t stride,
                                                                int D, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f;
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < D) {
         int b = sub;
-        for (; b + 4 < nblk; b += 8) {
+        for (; b + 24 < nblk; b += 32) {
             s0 += part[(size_t)b * stride + c];
-            s1 += part[(size_t)(b + 4) * stride + c];
+            s1 += part[(size_t)(b + 8) * stride + c];
+            s2 += part[(size_t)(b + 16) * stride + c];
+            s3 += part[(size_t)(b + 24) * stride + c];
         }
-        for (; b < nblk; b += 4) s0 += part[(size_t)b * stride + c];
+        for (; b < nblk; b += 8) s0 += part[(size_t)b * stride + c];
     }
-    red[sub][lane] = s0 + s1;
+    red[sub][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sub == 0 && c < D) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (sub == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][col];
+        out[c] = t;
+    }
 }
 
 // partial column sums: block (bx, by) sums rows [by*rpb, ...) of columns bx*256..
@@ -322,14 +329,14 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
     float* outs[3] = {dgamma, dbeta, dbias};
     if (dgamma && dbeta == dgamma + D && dbias == dbeta + D) {
         // the three outputs are one contiguous [3][D] buffer: a single finalize pass
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 64)), dim3(256), 0, st, part, nblk,
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 32)), dim3(256), 0, st, part, nblk,
                            (size_t)3 * D, 3 * D, dgamma);
         WF3D_LAUNCH_CHECK();
         return WF3D_OK;
     }
     for (int k = 0; k < 3; ++k) {
         if (!outs[k]) continue;
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 64)), dim3(256), 0, st, part + (size_t)k * D, nblk,
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part + (size_t)k * D, nblk,
                            (size_t)3 * D, D, outs[k]);
         WF3D_LAUNCH_CHECK();
     }
@@ -353,7 +360,7 @@ extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w,
     float* part = (float*)ws;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(wf3d_cdiv(D, 256), nrb), dim3(256), 0, st, x, R, D, ld, w, act, rpb, part);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 64)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
                        (size_t)D, D, out);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
