@@ -8,7 +8,7 @@ to wf3d.functional.EncoderFn (HIP kernels through the C ABI)."""
 import torch.nn as nn
 
 from wf3d import config
-from wf3d.functional import EncoderFn
+from wf3d.functional import EncoderFn, FusionFn
 
 
 def _point_block(n_in, n_out):
@@ -35,25 +35,29 @@ class PointNetEncoder(nn.Module):
         self._n_hidden = len(hidden_dims)
         self.precision = None          # None -> wf3d.config.precision() ("bf16x3" | "fp32")
 
-    def _param_list(self):
+    def _mlp_params(self):
         ps = []
         for i in range(self._n_hidden):
             lin, ln = self.mlp[4 * i], self.mlp[4 * i + 1]
             ps += [lin.weight, lin.bias, ln.weight, ln.bias]
         last = self.mlp[4 * self._n_hidden]
-        ps += [last.weight, last.bias]
+        return ps + [last.weight, last.bias]
+
+    def _fusion_params(self):
         ff = self.feature_fusion
-        ps += [ff[0].weight, ff[0].bias, ff[1].weight, ff[1].bias,
-               ff[3].weight, ff[3].bias, ff[4].weight, ff[4].bias,
-               ff[6].weight, ff[6].bias]
-        return ps
+        return [ff[0].weight, ff[0].bias, ff[1].weight, ff[1].bias,
+                ff[3].weight, ff[3].bias, ff[4].weight, ff[4].bias,
+                ff[6].weight, ff[6].bias]
 
     def encode(self, x):
         """(global, point_features, unmasked_mean, unmasked_max): the two extra
         pools are what VertexPredictor would recompute from point_features."""
         if x.dim() != 3:
             raise ValueError(f"expected (batch, num_points, input_dim), got {tuple(x.shape)}")
-        return EncoderFn.apply(x.float(), self._n_hidden, self.precision or config.precision(), *self._param_list())
+        pooled, pf, umean, umax = EncoderFn.apply(x.float(), self._n_hidden, self.precision or config.precision(),
+                                                  *self._mlp_params())
+        g = FusionFn.apply(pooled, *self._fusion_params())
+        return g, pf, umean, umax
 
     def forward(self, x):
         g, pf, _, _ = self.encode(x)

@@ -37,12 +37,14 @@ def _split_ok(rows, k, split):
 
 
 class EncoderFn(torch.autograd.Function):
-    """x[B,N,Din], params -> (global[B,C], point_features[B,N,C], umean[B,C], umax[B,C]).
+    """x[B,N,Din], params -> (pooled[B,2C] = [masked max | masked mean], point_features[B,N,C],
+    umean[B,C], umax[B,C]).
 
-    params = [W_i, b_i, gamma_i, beta_i]*n_hidden + [W_out, b_out]
-             + [F0w, F0b, F1g, F1b, F3w, F3b, F4g, F4b, F6w, F6b]
-    umean/umax are the UNMASKED pools the vertex head needs
-    (VertexPredictor.py:86-87), produced by the same pass as the masked ones.
+    params = [W_i, b_i, gamma_i, beta_i]*n_hidden + [W_out, b_out]   (the per-point shared MLP)
+    umean/umax are the UNMASKED pools the vertex head needs (VertexPredictor.py:86-87), produced
+    by the same pass as the masked ones.  The fusion MLP is its own Function (FusionFn) so that
+    its gradients are handed to autograd — and to the data-parallel reducer — before the long
+    per-point backward starts.
 
     precision "bf16x3": layers whose input width is a multiple of 8 consume the previous
     layer's relu(LN(z)) as an sx8 split operand produced by wf3d_ln_prep (which also
@@ -86,40 +88,19 @@ class EncoderFn(torch.autograd.Function):
         C = pf.shape[1]
         mmax, mavg, umean, umax, arg_m, arg_u, cnt = ops.pool4_fwd(pf.view(B, N, C), valid)
         pooled = torch.cat([mmax, mavg], dim=1)                           # max first (PointNetEncoder.py:115)
-        F = params[4 * n_hidden + 2:]
-        f0 = ops.gemm(pooled, F[0], NT, bias=F[1])
-        s0 = ops.row_stats(f0)
-        f3 = ops.gemm(f0, F[4], NT, bias=F[5], pro=Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
-        s3 = ops.row_stats(f3)
-        gl = ops.gemm(f3, F[8], NT, bias=F[9], pro=Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
         ctx.n_hidden, ctx.dims, ctx.split = n_hidden, (B, N, C), split
         ctx.params = params
-        ctx.saved = (x2, valid, zs, stats, hs, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt)
+        ctx.saved = (x2, valid, zs, stats, hs, arg_m, arg_u, cnt)
         pf3 = pf.view(B, N, C)
-        return gl, pf3, umean, umax
+        return pooled, pf3, umean, umax
 
     @staticmethod
-    def backward(ctx, dgl, dpf, dumean, dumax):
+    def backward(ctx, dpooled, dpf, dumean, dumax):
         nh, (B, N, C), split = ctx.n_hidden, ctx.dims, ctx.split
         M = B * N
         params = ctx.params
-        x2, valid, zs, stats, hs, pooled, f0, s0, f3, s3, arg_m, arg_u, cnt = ctx.saved
-        F = params[4 * nh + 2:]
+        x2, valid, zs, stats, hs, arg_m, arg_u, cnt = ctx.saved
         grads = [None] * len(params)
-        gF = 4 * nh + 2
-        dpooled = None
-        if dgl is not None:
-            dgl = dgl.contiguous()
-            # fusion MLP backward
-            grads[gF + 9] = ops.colsum(dgl)
-            grads[gF + 8], dh = _lin_bwd(dgl, f3, F[8], Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
-            dz, grads[gF + 6], grads[gF + 7], grads[gF + 5] = ops.ln_act_bwd(dh, f3, s3[0], s3[1], F[6], F[7], ACT_RELU, inplace=True)
-            grads[gF + 4], dh = _lin_bwd(dz, f0, F[4], Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
-            dz, grads[gF + 2], grads[gF + 3], grads[gF + 1] = ops.ln_act_bwd(dh, f0, s0[0], s0[1], F[2], F[3], ACT_RELU, inplace=True)
-            grads[gF + 0], dpooled = _lin_bwd(dz, pooled, F[0], None)
-        else:
-            for k in range(10):
-                grads[gF + k] = torch.zeros_like(F[k])
         dmmax = dpooled[:, :C].contiguous() if dpooled is not None else None
         dmavg = dpooled[:, C:].contiguous() if dpooled is not None else None
         if dpf is not None:
@@ -173,6 +154,37 @@ class EncoderFn(torch.autograd.Function):
             dz = dz_s = None
         ctx.saved = None
         return (None, None, None, *grads)
+
+
+class FusionFn(torch.autograd.Function):
+    """pooled[B,2C] -> global[B,C]: feature_fusion (PointNetEncoder.py:57-65,116).
+    params = [F0w, F0b, F1g, F1b, F3w, F3b, F4g, F4b, F6w, F6b]"""
+
+    @staticmethod
+    def forward(ctx, pooled, *F):
+        pooled = pooled.contiguous()
+        f0 = ops.gemm(pooled, F[0], NT, bias=F[1])
+        s0 = ops.row_stats(f0)
+        f3 = ops.gemm(f0, F[4], NT, bias=F[5], pro=Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
+        s3 = ops.row_stats(f3)
+        gl = ops.gemm(f3, F[8], NT, bias=F[9], pro=Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
+        ctx.params, ctx.saved = F, (pooled, f0, s0, f3, s3)
+        return gl
+
+    @staticmethod
+    def backward(ctx, dgl):
+        F = ctx.params
+        pooled, f0, s0, f3, s3 = ctx.saved
+        G = [None] * 10
+        dgl = dgl.contiguous()
+        G[9] = ops.colsum(dgl)
+        G[8], dh = _lin_bwd(dgl, f3, F[8], Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
+        dz, G[6], G[7], G[5] = ops.ln_act_bwd(dh, f3, s3[0], s3[1], F[6], F[7], ACT_RELU, inplace=True)
+        G[4], dh = _lin_bwd(dz, f0, F[4], Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
+        dz, G[2], G[3], G[1] = ops.ln_act_bwd(dh, f0, s0[0], s0[1], F[2], F[3], ACT_RELU, inplace=True)
+        G[0], dpooled = _lin_bwd(dz, pooled, F[0], None)
+        ctx.saved = None
+        return (dpooled, *G)
 
 
 # ===========================================================================
