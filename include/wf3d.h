@@ -201,11 +201,13 @@ int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V
 
 /* 8-head self-attention of nn.MultiheadAttention (EdgePredictor.py:41-46,109):
  * qkv[Rv, 3E] packed in_proj output; one workgroup per (head, sample); writes
- * ctx[Rv, E] (heads concatenated, before out_proj) and lse[Rv, heads]. */
+ * ctx[Rv, E] (heads concatenated, before out_proj) and lse[Rv, heads].  head_dim 64
+ * runs QK^T and PV (and the five backward contractions) on fp32 MFMA; backward takes
+ * the forward's ctx (delta_i = dctx_i · ctx_i). */
 int wf3d_attn_fwd(const float* qkv, const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
                   uint32_t drop_seed, float* ctx, float* lse, void* stream);
-int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* lse, const int32_t* voff, int S, int vmax,
-                  int E, int heads, float drop_p, uint32_t drop_seed, float* dqkv, void* stream);
+int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* ctx, const float* lse, const int32_t* voff,
+                  int S, int vmax, int E, int heads, float drop_p, uint32_t drop_seed, float* dqkv, void* stream);
 
 /* Split first layer of edge_mlp (EdgePredictor.py:122-137):
  * pre[e,:] = Pa[i,:] + Pb[j,:] + |c_i - c_j| * wdelta  for edge e = (i, j), plus

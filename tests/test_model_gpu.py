@@ -229,17 +229,17 @@ def test_edge_head_dropout_gradcheck(precision):
     assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd.item(), an.item())
 
 
-def test_attention_vs_torch_mha():
+@pytest.mark.parametrize("E,heads", [(128, 4), (256, 4), (512, 8)])      # head_dim 32 (VALU) and 64 (MFMA)
+def test_attention_vs_torch_mha(E, heads):
     """wf3d_attn_fwd/bwd against torch's own MultiheadAttention math on ragged samples."""
     from wf3d import ops
     torch.manual_seed(0)
-    E, heads = 128, 4
     counts = [5, 64, 130, 256, 2]
     meta = ops.EdgeMeta.get(counts, dev())
     qkv = torch.randn(meta.Rv, 3 * E, device=dev())
     dctx = torch.randn(meta.Rv, E, device=dev())
     ctx, lse = ops.attn_fwd(qkv, meta, E, heads)
-    dqkv = ops.attn_bwd(qkv, dctx, lse, meta, E, heads)
+    dqkv = ops.attn_bwd(qkv, dctx, ctx, lse, meta, E, heads)
     q64 = qkv.double().cpu().requires_grad_()
     outs = []
     off = 0

@@ -11,11 +11,19 @@
 //
 // Vertex rows are COMPACT: sample s owns rows voff[s] .. voff[s+1]-1 of every
 // [Rv, *] matrix, so ragged batches cost nothing and no key mask is needed.
+#include <stdlib.h>
+
 #include "wf3d_common.h"
 
 namespace {
 
 constexpr int ATT_WAVES = 4;
+
+// head_dim 64 runs on the matrix cores (attn_mfma.hip); WF3D_ATTN_MFMA=0 forces the VALU kernels below
+bool use_mfma(int E, int heads) {
+    static const int on = [] { const char* e = getenv("WF3D_ATTN_MFMA"); return e ? atoi(e) : 1; }();
+    return on && E / heads == 64;
+}
 
 struct AttnParams {
     const float* qkv;      // [Rv, 3E]
@@ -255,6 +263,7 @@ extern "C" int wf3d_attn_fwd(const float* qkv, const int32_t* voff, int S, int v
     if (S == 0 || vmax == 0) return WF3D_OK;
     WF3D_CHECK(qkv && voff && ctx && lse, WF3D_ERR_ARG, "wf3d_attn_fwd: null pointer");
     WF3D_CHECK(drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_attn_fwd: bad drop_p");
+    if (use_mfma(E, heads)) return wf3d_attn_fwd_mfma(qkv, voff, S, vmax, E, heads, drop_p, drop_seed, ctx, lse, stream);
     AttnParams p{};
     p.qkv = qkv; p.ctx = ctx; p.lse = lse; p.voff = voff;
     p.E = E; p.heads = heads; p.hd = E / heads; p.vmax = vmax;
@@ -270,14 +279,16 @@ extern "C" int wf3d_attn_fwd(const float* qkv, const int32_t* voff, int S, int v
     return WF3D_OK;
 }
 
-extern "C" int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* lse, const int32_t* voff, int S,
-                             int vmax, int E, int heads, float drop_p, uint32_t drop_seed, float* dqkv,
-                             void* stream) {
+extern "C" int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* ctx, const float* lse,
+                             const int32_t* voff, int S, int vmax, int E, int heads, float drop_p, uint32_t drop_seed,
+                             float* dqkv, void* stream) {
     int rc = attn_check("wf3d_attn_bwd", S, E, heads, vmax, true);
     if (rc) return rc;
     if (S == 0 || vmax == 0) return WF3D_OK;
-    WF3D_CHECK(qkv && dctx && lse && voff && dqkv, WF3D_ERR_ARG, "wf3d_attn_bwd: null pointer");
+    WF3D_CHECK(qkv && dctx && ctx && lse && voff && dqkv, WF3D_ERR_ARG, "wf3d_attn_bwd: null pointer");
     WF3D_CHECK(drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_attn_bwd: bad drop_p");
+    if (use_mfma(E, heads))
+        return wf3d_attn_bwd_mfma(qkv, dctx, ctx, lse, voff, S, vmax, E, heads, drop_p, drop_seed, dqkv, stream);
     AttnParams p{};
     p.qkv = qkv; p.dctx = dctx; p.lse = (float*)lse; p.dqkv = dqkv; p.voff = voff;
     p.E = E; p.heads = heads; p.hd = E / heads; p.vmax = vmax;

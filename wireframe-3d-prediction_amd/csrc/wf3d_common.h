@@ -37,6 +37,13 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
                                    int K, int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes,
                                    void* stream);
 
+// internal: MFMA attention for head_dim 64 (attn_mfma.hip)
+extern "C" int wf3d_attn_fwd_mfma(const float* qkv, const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
+                                  uint32_t drop_seed, float* ctx, float* lse, void* stream);
+extern "C" int wf3d_attn_bwd_mfma(const float* qkv, const float* dctx, const float* ctx, const float* lse,
+                                  const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
+                                  uint32_t drop_seed, float* dqkv, void* stream);
+
 static inline int wf3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers --------------------------------------------------------

@@ -72,8 +72,8 @@ SIGNATURES = {
     "wf3d_edge_scatter_dverts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_attn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p,
                               c_void_p]),
-    "wf3d_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u32,
-                              c_void_p, c_void_p]),
+    "wf3d_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                              c_u32, c_void_p, c_void_p]),
     "wf3d_edge_pair_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf3d_edge_pair_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

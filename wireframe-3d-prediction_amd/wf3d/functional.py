@@ -385,7 +385,7 @@ class EdgeFn(torch.autograd.Function):
         # F = f + out_proj(ctx)
         G[11] = ops.colsum(dF)
         G[10], dcx = _lin_bwd(dF, cx, Ow, None)
-        dqkv = ops.attn_bwd(qkv, dcx, lse, meta, H, heads, pa_, sd[1])
+        dqkv = ops.attn_bwd(qkv, dcx, cx, lse, meta, H, heads, pa_, sd[1])
         G[9] = ops.colsum(dqkv)
         G[8] = ops.gemm(dqkv, f, TN)
         df = ops.gemm(dqkv, Aw, NN, addend=dF)

@@ -309,12 +309,12 @@ def attn_fwd(qkv, meta, E, heads, drop_p=0.0, seed=0):
     return ctx, lse
 
 
-def attn_bwd(qkv, dctx, lse, meta, E, heads, drop_p=0.0, seed=0):
-    _need_cuda(qkv, dctx, lse)
-    if not dctx.is_contiguous():
-        raise RuntimeError("wf3d.attn_bwd: contiguous dctx required")
+def attn_bwd(qkv, dctx, ctx, lse, meta, E, heads, drop_p=0.0, seed=0):
+    _need_cuda(qkv, dctx, ctx, lse)
+    if not (dctx.is_contiguous() and ctx.is_contiguous()):
+        raise RuntimeError("wf3d.attn_bwd: contiguous dctx / ctx required")
     dqkv = torch.empty_like(qkv)
-    check(_lib.load().wf3d_attn_bwd(_p(qkv), _p(dctx), _p(lse), _p(meta.voff), meta.B, meta.vmax, E, heads,
+    check(_lib.load().wf3d_attn_bwd(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(meta.voff), meta.B, meta.vmax, E, heads,
                                     float(drop_p), int(seed) & 0xFFFFFFFF, _p(dqkv), _stream()), "attn_bwd")
     return dqkv
 
