@@ -229,6 +229,23 @@ int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, const int32_t* e
 int wf3d_edge_prob_bwd(const float* probs, const float* dprobs, const int32_t* eoff, const int32_t* esample, int Re,
                        int max_e, float* dlogit, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Row f-1 (next row after the hot path): losses/WireframeLoss.py — the
+ * caller of backward.  cost: all B Hungarian cost matrices in one launch
+ * (WireframeLoss.py:142-219; the assignment itself stays scipy on the host, :236);
+ * terms: SmoothL1 over matched pairs + BCE(existence) + BCE(edges over the common
+ * width) and their gradients w.r.t. vertices / existence / edge_probs (:60-104,241-283).
+ * losses[4] = {vertex, existence, edge, weighted total}.
+ * ------------------------------------------------------------------------ */
+int wf3d_loss_cost_matrix(const float* verts, long sample_stride, long vertex_stride, const float* exist,
+                          const float* tverts, int Vt, const int64_t* counts, int B, int V, float* cost,
+                          void* stream);
+int wf3d_loss_terms(const float* verts, long sample_stride, long vertex_stride, const float* exist,
+                    const float* edge, int Ep, const float* tverts, int Vt, const float* texist,
+                    const float* tlabel, int Et, const int32_t* m_pred, const int32_t* m_tgt, const int32_t* m_off,
+                    int n_match, int B, int V, float w_vertex, float w_exist, float w_edge, float* dverts,
+                    float* dexist, float* dedge, float* losses, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,84 @@
+"""Row f-1 (WireframeLoss): the CPU oracle against the reference-generated fixtures (CPU), and the
+device implementation against the same fixtures (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from helpers import detgen
+from oracle import loss_cpu
+
+CASES = ["loss_a", "loss_b", "loss_c"]
+
+
+def build(tag, device="cpu"):
+    g = H.load_golden(tag)
+    B, V, seed = int(g["meta.B"]), int(g["meta.V"]), int(g["meta.seed"])
+    ep, et = int(g["meta.max_e_pred"]), int(g["meta.max_e_tgt"])
+    pv = torch.from_numpy(detgen.normalish(tag + ".pv", (B, V, 3), seed)).to(device).requires_grad_()
+    pe = torch.sigmoid(torch.from_numpy(2.0 * detgen.normalish(tag + ".pe", (B, V), seed))).to(device).requires_grad_()
+    pp = torch.sigmoid(torch.from_numpy(2.0 * detgen.normalish(tag + ".pp", (B, ep), seed))).to(device).requires_grad_()
+    tv = torch.from_numpy(detgen.normalish(tag + ".tv", (B, V, 3), seed)).to(device)
+    cnt = torch.tensor(g["meta.counts"].tolist(), dtype=torch.long, device=device)
+    te = (torch.arange(V, device=device)[None, :] < cnt[:, None]).float()
+    tl = (torch.from_numpy(detgen.uniform(tag + ".tl", (B, et), 0, 1, seed)) > 0.7).float().to(device)
+    preds = {"vertices": pv, "existence_probabilities": pe, "edge_probs": pp}
+    tgts = {"vertices": tv, "vertex_existence": te, "edge_labels": tl, "vertex_counts": cnt}
+    return g, preds, tgts
+
+
+def check(g, out, matches, preds, tol):
+    for k in ("total_loss", "vertex_loss", "existence_loss", "edge_loss"):
+        assert abs(float(out[k]) - float(g["out." + k])) < tol * max(1.0, abs(float(g["out." + k]))), k
+    assert [len(m[0]) for m in matches] == g["match.lens"].tolist()
+    assert np.array_equal(np.concatenate([np.asarray(m[0]) for m in matches]), g["match.pred"])     # bit-exact assignment
+    assert np.array_equal(np.concatenate([np.asarray(m[1]) for m in matches]), g["match.tgt"])
+    out["total_loss"].backward()
+    for name, key in (("vertices", "grad.vertices"), ("existence_probabilities", "grad.existence"), ("edge_probs", "grad.edge_probs")):
+        assert H.rel_err(preds[name].grad.cpu().numpy(), g[key]) < 10 * tol, name
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_loss_oracle_matches_reference_fixture(tag):
+    g, preds, tgts = build(tag)
+    wv, wd, we = g["meta.weights"].tolist()
+    out, matches = loss_cpu.wireframe_loss(preds, tgts, vertex_weight=wv, edge_weight=wd, existence_weight=we)
+    check(g, out, matches, preds, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_device_loss_matches_reference_fixture(tag):
+    from losses.WireframeLoss import WireframeLoss
+    g, preds, tgts = build(tag, "cuda:0")
+    wv, wd, we = g["meta.weights"].tolist()
+    crit = WireframeLoss(vertex_weight=wv, edge_weight=wd, existence_weight=we)
+    out = crit(preds, tgts)
+    assert set(out) == {"total_loss", "vertex_loss", "existence_loss", "edge_loss"}
+    matches = crit._hungarian_matching(preds, tgts)
+    check(g, out, matches, preds, 2e-6)
+
+
+@pytest.mark.gpu
+def test_device_loss_drives_the_model_backward():
+    """total_loss.backward() through the drop-in model, strided `vertices` view included."""
+    from losses.WireframeLoss import WireframeLoss
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, N, V = 3, 256, 12
+    model = PointCloudToWireframe(8, V).to(dev).set_dropout(0.0)
+    model.train()
+    x = torch.randn(B, N, 8, device=dev)
+    cnt = torch.tensor([12, 3, 7], device=dev)
+    out = model(x, cnt)
+    tg = {"vertices": torch.randn(B, V, 3, device=dev), "vertex_existence": (torch.arange(V, device=dev)[None] < cnt[:, None]).float(),
+          "edge_labels": (torch.rand(B, V * (V - 1) // 2, device=dev) > 0.8).float(), "vertex_counts": cnt}
+    crit = WireframeLoss(3.0, 1.5, 1.0)
+    ld = crit(out, tg)
+    ld["total_loss"].backward()
+    # same numbers from the CPU oracle loss on the same predictions
+    preds_cpu = {k: out[k].detach().cpu().requires_grad_() for k in ("vertices", "existence_probabilities", "edge_probs")}
+    ref, _ = loss_cpu.wireframe_loss(preds_cpu, {k: v.cpu() for k, v in tg.items()}, 3.0, 1.5, 1.0)
+    assert abs(float(ld["total_loss"]) - float(ref["total_loss"])) < 1e-5 * float(ref["total_loss"])
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "spatial_proj" not in n)

@@ -463,3 +463,38 @@ def gemm_split_tn(a_s, b_s, out=None, accumulate=False):
                                  1 if accumulate else 0, _p(ws), ws.numel() if ws is not None else 0, _stream()),
           "gemm_split_tn")
     return out
+
+
+# ---------------------------------------------------------------------------
+# row f-1: WireframeLoss on device
+# ---------------------------------------------------------------------------
+def loss_cost_matrix(verts, exist, tverts, counts):
+    """verts [B,V,3] (view ok), exist [B,V], tverts [B,Vt,3], counts int64 [B] -> cost [B,V,V]."""
+    _need_cuda(verts, exist, tverts, counts)
+    if verts.stride(2) != 1 or not exist.is_contiguous() or not tverts.is_contiguous() or counts.dtype != torch.int64:
+        raise RuntimeError("wf3d.loss_cost_matrix: bad layout / dtype")
+    B, V, _ = verts.shape
+    cost = torch.empty(B, V, V, dtype=torch.float32, device=verts.device)
+    check(_lib.load().wf3d_loss_cost_matrix(_p(verts), verts.stride(0), verts.stride(1), _p(exist), _p(tverts),
+                                            tverts.shape[1], _p(counts), B, V, _p(cost), _stream()), "loss_cost_matrix")
+    return cost
+
+
+def loss_terms(verts, exist, edge, tverts, texist, tlabel, m_pred, m_tgt, m_off, n_match, weights):
+    """Returns (losses[4] = vertex, existence, edge, total; dverts [B,V,3]; dexist [B,V]; dedge [B,Ep])."""
+    _need_cuda(verts, exist, edge, tverts, texist, tlabel, m_pred, m_tgt, m_off)
+    B, V, _ = verts.shape
+    Ep = edge.shape[1] if edge is not None else 0
+    Et = tlabel.shape[1] if tlabel is not None else 0
+    dev = verts.device
+    dverts = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dexist = torch.empty(B, V, dtype=torch.float32, device=dev)
+    dedge = torch.empty(B, Ep, dtype=torch.float32, device=dev)
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    ws = scratch(B * 3 * 4, dev)
+    check(_lib.load().wf3d_loss_terms(_p(verts), verts.stride(0), verts.stride(1), _p(exist), _p(edge), Ep, _p(tverts),
+                                      tverts.shape[1], _p(texist), _p(tlabel), Et, _p(m_pred), _p(m_tgt), _p(m_off),
+                                      int(n_match), B, V, float(weights[0]), float(weights[1]), float(weights[2]),
+                                      _p(dverts), _p(dexist), _p(dedge), _p(losses), _p(ws), ws.numel(), _stream()),
+          "loss_terms")
+    return losses, dverts, dexist, dedge
