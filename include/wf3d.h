@@ -240,6 +240,16 @@ int wf3d_edge_prob_bwd(const float* probs, const float* dprobs, const int32_t* e
 int wf3d_loss_cost_matrix(const float* verts, long sample_stride, long vertex_stride, const float* exist,
                           const float* tverts, int Vt, const int64_t* counts, int B, int V, float* cost,
                           void* stream);
+/* Hungarian assignment on the device (Jonker-Volgenant shortest augmenting paths, fp64 duals,
+ * one wave per sample) — replaces scipy.optimize.linear_sum_assignment + the per-sample
+ * .cpu().numpy() sync of WireframeLoss.py:235-236.  col4row[b,p] = column of prediction p;
+ * p is matched to a real target iff col4row[b,p] < counts[b]. */
+int wf3d_loss_assign(const float* cost, int B, int V, int32_t* col4row, void* stream);
+int wf3d_loss_terms_assigned(const float* verts, long sample_stride, long vertex_stride, const float* exist,
+                             const float* edge, int Ep, const float* tverts, int Vt, const float* texist,
+                             const float* tlabel, int Et, const int32_t* col4row, const int64_t* counts, int B, int V,
+                             float w_vertex, float w_exist, float w_edge, float* dverts, float* dexist, float* dedge,
+                             float* losses, void* ws, size_t ws_bytes, void* stream);
 int wf3d_loss_terms(const float* verts, long sample_stride, long vertex_stride, const float* exist,
                     const float* edge, int Ep, const float* tverts, int Vt, const float* texist,
                     const float* tlabel, int Et, const int32_t* m_pred, const int32_t* m_tgt, const int32_t* m_off,

@@ -47,12 +47,38 @@ def test_loss_oracle_matches_reference_fixture(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("V,B", [(2, 3), (7, 5), (26, 4), (64, 32), (200, 3), (256, 2)])
+def test_device_assignment_is_optimal_like_scipy(V, B):
+    """Device Jonker-Volgenant vs scipy on wireframe-shaped cost matrices (real + identical dummy columns)."""
+    from scipy.optimize import linear_sum_assignment
+    from wf3d import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(V * 31 + B)
+    pv, tv = torch.randn(B, V, 3, generator=g).to(dev), torch.randn(B, V, 3, generator=g).to(dev)
+    pe = torch.rand(B, V, generator=g).to(dev)
+    counts = torch.randint(0, V + 1, (B,), generator=g).to(dev)
+    counts[0] = V
+    cost = ops.loss_cost_matrix(pv, pe, tv, counts)
+    c4r = ops.loss_assign(cost).cpu().numpy()
+    cn, cnt = cost.cpu().numpy().astype(np.float64), counts.cpu().tolist()
+    for b in range(B):
+        assert sorted(c4r[b].tolist()) == list(range(V))                      # a permutation
+        ri, ci = linear_sum_assignment(cn[b])
+        ours = cn[b][np.arange(V), c4r[b]].sum()
+        assert abs(ours - cn[b][ri, ci].sum()) <= 1e-9 * max(1.0, abs(ours))     # same optimum
+        real_ref = {(int(r), int(c)) for r, c in zip(ri, ci) if c < cnt[b]}
+        real_our = {(p, int(c4r[b][p])) for p in range(V) if c4r[b][p] < cnt[b]}
+        assert real_ref == real_our                                           # same matches to real targets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assignment", ["device", "scipy"])
 @pytest.mark.parametrize("tag", CASES)
-def test_device_loss_matches_reference_fixture(tag):
+def test_device_loss_matches_reference_fixture(tag, assignment):
     from losses.WireframeLoss import WireframeLoss
     g, preds, tgts = build(tag, "cuda:0")
     wv, wd, we = g["meta.weights"].tolist()
-    crit = WireframeLoss(vertex_weight=wv, edge_weight=wd, existence_weight=we)
+    crit = WireframeLoss(vertex_weight=wv, edge_weight=wd, existence_weight=we, assignment=assignment)
     out = crit(preds, tgts)
     assert set(out) == {"total_loss", "vertex_loss", "existence_loss", "edge_loss"}
     matches = crit._hungarian_matching(preds, tgts)

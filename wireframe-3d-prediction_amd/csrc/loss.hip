@@ -103,6 +103,151 @@ __global__ void loss_final_kernel(const float* __restrict__ part, int B, float n
     out[0] = lv; out[1] = le; out[2] = ld; out[3] = wv * lv + we * le + wd * ld;
 }
 
+
+// ---------------------------------------------------------------------------
+// Linear sum assignment on the device: shortest-augmenting-path (Jonker-Volgenant, the
+// algorithm behind scipy.optimize.linear_sum_assignment) on a square [V, V] cost matrix, one
+// wave64 per sample, lanes = columns (V <= 256: up to 4 columns per lane), dual variables and
+// path costs in fp64 like scipy.  Removes the loss's only device->host sync: with it the
+// whole train step is asynchronous.  Output col4row[b, p] = column assigned to prediction p.
+// Ties: a lane-order rule (unassigned column first, then lowest index); the dummy columns of
+// the wireframe cost are identical, so only assignments to real targets are meaningful and
+// those are unique whenever the optimum is.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost, int V, int32_t* __restrict__ col4row_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    double* u = reinterpret_cast<double*>(lsm);            // [V] row duals
+    double* v = u + V;                                     // [V] column duals
+    double* spc = v + V;                                   // [V] shortest path costs
+    int* path = reinterpret_cast<int*>(spc + V);           // [V]
+    int* row4col = path + V;                               // [V]
+    int* col4row = row4col + V;                            // [V]
+    int* srlist = col4row + V;                             // [V]
+    unsigned char* in_sc = reinterpret_cast<unsigned char*>(srlist + V);   // [V]
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const float* C = cost + (size_t)b * V * V;
+    for (int j = lane; j < V; j += 64) { u[j] = 0.0; v[j] = 0.0; row4col[j] = -1; col4row[j] = -1; }
+    __syncthreads();
+    for (int cur = 0; cur < V; ++cur) {
+        for (int j = lane; j < V; j += 64) { spc[j] = INFINITY; in_sc[j] = 0; }
+        __syncthreads();
+        int i = cur, sink = -1, nsr = 0;
+        double min_val = 0.0;
+        while (sink < 0) {
+            if (lane == 0) srlist[nsr] = i;
+            ++nsr;
+            const double ui = u[i];
+            double best = INFINITY;
+            int bestj = 0x7fffffff, best_free = 0;
+            for (int j = lane; j < V; j += 64) {
+                if (in_sc[j]) continue;
+                const double r = min_val + (double)C[(size_t)i * V + j] - ui - v[j];
+                double cur_spc = spc[j];
+                if (r < cur_spc) { cur_spc = r; spc[j] = r; path[j] = i; }
+                const int fr = row4col[j] < 0;
+                if (cur_spc < best || (cur_spc == best && (fr > best_free || (fr == best_free && j < bestj)))) {
+                    best = cur_spc; bestj = j; best_free = fr;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int oj = __shfl_xor(bestj, o, 64), of = __shfl_xor(best_free, o, 64);
+                if (ob < best || (ob == best && (of > best_free || (of == best_free && oj < bestj)))) {
+                    best = ob; bestj = oj; best_free = of;
+                }
+            }
+            min_val = best;
+            if (lane == 0) in_sc[bestj] = 1;
+            __syncthreads();
+            const int r4c = row4col[bestj];
+            if (r4c < 0) sink = bestj; else i = r4c;
+        }
+        // dual update
+        for (int k = lane; k < nsr; k += 64) {
+            const int r = srlist[k];
+            u[r] += (r == cur) ? min_val : min_val - spc[col4row[r]];
+        }
+        for (int j = lane; j < V; j += 64)
+            if (in_sc[j]) v[j] -= min_val - spc[j];
+        __syncthreads();
+        // augment along the path (sequential, wave-uniform)
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int r = path[j];
+                row4col[j] = r;
+                const int prev = col4row[r];
+                col4row[r] = j;
+                j = prev;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    for (int p = lane; p < V; p += 64) col4row_out[(size_t)b * V + p] = col4row[p];
+}
+
+// loss terms from the device assignment: prediction p of sample b is matched iff col4row[b,p] < count[b]
+__global__ __launch_bounds__(256) void loss_terms_dev_kernel(const float* __restrict__ verts, long vs_b, long vs_v,
+                                                              const float* __restrict__ exist,
+                                                              const float* __restrict__ edge, int Ep,
+                                                              const float* __restrict__ tverts, int Vt,
+                                                              const float* __restrict__ texist,
+                                                              const float* __restrict__ tlabel, int Et, int min_e,
+                                                              const int32_t* __restrict__ col4row,
+                                                              const int64_t* __restrict__ counts, int V, int B,
+                                                              float wv, float ge, float gd,
+                                                              float* __restrict__ dverts, float* __restrict__ dexist,
+                                                              float* __restrict__ dedge, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    long nm = 0;
+    for (int s = 0; s < B; ++s) nm += min((long)counts[s], (long)V);        // total matches = sum of real targets
+    const float gv = nm > 0 ? wv / (3.0f * (float)nm) : 0.f;
+    const int cnt = (int)counts[b];
+    float sv = 0.f;
+    for (int p = tid; p < V; p += 256) {
+        const int t = col4row[(size_t)b * V + p];
+        const bool m = t < cnt;
+        const float* vp = verts + (size_t)b * vs_b + (size_t)p * vs_v;
+        const float* w = tverts + ((size_t)b * Vt + (m ? t : 0)) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float g = 0.f;
+            if (m) {
+                const float d = vp[k] - w[k], a = fabsf(d);
+                sv += a < 1.0f ? 0.5f * d * d : a - 0.5f;
+                g = gv * (a < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f));
+            }
+            dverts[((size_t)b * V + p) * 3 + k] = g;
+        }
+    }
+    float se = 0.f;
+    for (int i = tid; i < V; i += 256) {
+        float g;
+        se += bce(exist[(size_t)b * V + i], texist[(size_t)b * V + i], g);
+        dexist[(size_t)b * V + i] = ge * g;
+    }
+    float sd = 0.f;
+    for (int i = tid; i < Ep; i += 256) {
+        float g = 0.f;
+        if (i < min_e) sd += bce(edge[(size_t)b * Ep + i], tlabel[(size_t)b * Et + i], g);
+        dedge[(size_t)b * Ep + i] = gd * g;
+    }
+    sv = block_sum(sv, red); se = block_sum(se, red); sd = block_sum(sd, red);
+    if (tid == 0) { part[b * 3] = sv; part[b * 3 + 1] = se; part[b * 3 + 2] = sd; }
+}
+
+__global__ void loss_final_dev_kernel(const float* __restrict__ part, const int64_t* __restrict__ counts, int B, int V,
+                                      float ne, float nd, float wv, float we, float wd, float* __restrict__ out) {
+    float sv = 0.f, se = 0.f, sd = 0.f;
+    long nm = 0;
+    for (int b = 0; b < B; ++b) { sv += part[b * 3]; se += part[b * 3 + 1]; sd += part[b * 3 + 2]; nm += min((long)counts[b], (long)V); }
+    const float lv = nm > 0 ? sv / (3.0f * (float)nm) : 0.f, le = ne > 0.f ? se / ne : 0.f, ld = nd > 0.f ? sd / nd : 0.f;
+    out[0] = lv; out[1] = le; out[2] = ld; out[3] = wv * lv + we * le + wd * ld;
+}
+
 }  // namespace
 
 extern "C" int wf3d_loss_cost_matrix(const float* verts, long sample_stride, long vertex_stride, const float* exist,
@@ -138,6 +283,42 @@ extern "C" int wf3d_loss_terms(const float* verts, long sample_stride, long vert
     WF3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, st, (const float*)ws, B, nv, ne, nd, w_vertex, w_exist,
                        w_edge, losses);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_loss_assign(const float* cost, int B, int V, int32_t* col4row, void* stream) {
+    WF3D_CHECK(B >= 0 && V > 0, WF3D_ERR_ARG, "wf3d_loss_assign: bad dims");
+    WF3D_CHECK(V <= 1024, WF3D_ERR_UNSUPPORTED, "wf3d_loss_assign: V > 1024");
+    if (B == 0) return WF3D_OK;
+    WF3D_CHECK(cost && col4row, WF3D_ERR_ARG, "wf3d_loss_assign: null pointer");
+    const size_t lds = (size_t)V * (3 * sizeof(double) + 4 * sizeof(int) + 1) + 16;
+    hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cost, V, col4row);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_loss_terms_assigned(const float* verts, long sample_stride, long vertex_stride, const float* exist,
+                                        const float* edge, int Ep, const float* tverts, int Vt, const float* texist,
+                                        const float* tlabel, int Et, const int32_t* col4row, const int64_t* counts,
+                                        int B, int V, float w_vertex, float w_exist, float w_edge, float* dverts,
+                                        float* dexist, float* dedge, float* losses, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    WF3D_CHECK(B > 0 && V > 0 && Ep >= 0 && Et >= 0, WF3D_ERR_ARG, "wf3d_loss_terms_assigned: bad dims");
+    WF3D_CHECK(verts && exist && tverts && texist && col4row && counts && dverts && dexist && losses, WF3D_ERR_ARG,
+               "wf3d_loss_terms_assigned: null pointer");
+    WF3D_CHECK(Ep == 0 || (edge && dedge), WF3D_ERR_ARG, "wf3d_loss_terms_assigned: null edge tensors");
+    WF3D_CHECK(ws && ws_bytes >= (size_t)B * 3 * sizeof(float), WF3D_ERR_WS, "wf3d_loss_terms_assigned: workspace too small");
+    const int min_e = (Ep > 0 && Et > 0 && tlabel) ? (Ep < Et ? Ep : Et) : 0;
+    const float ne = (float)B * V, nd = (float)B * min_e;
+    const float ge = w_exist / ne, gd = min_e ? w_edge / nd : 0.f;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_terms_dev_kernel, dim3(B), dim3(256), 0, st, verts, sample_stride, vertex_stride, exist, edge,
+                       Ep, tverts, Vt, texist, tlabel, Et, min_e, col4row, counts, V, B, w_vertex, ge, gd, dverts, dexist,
+                       dedge, (float*)ws);
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_final_dev_kernel, dim3(1), dim3(1), 0, st, (const float*)ws, counts, B, V, ne, nd, w_vertex,
+                       w_exist, w_edge, losses);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

@@ -14,6 +14,26 @@ from scipy.optimize import linear_sum_assignment
 from wf3d import ops
 
 
+class _LossDevFn(torch.autograd.Function):
+    """Fully asynchronous variant: cost matrices, assignment, loss terms and gradients all on the device."""
+
+    @staticmethod
+    def forward(ctx, verts, exist, edge, tverts, texist, tlabel, counts, weights):
+        exist_c = exist.contiguous()
+        cost = ops.loss_cost_matrix(verts, exist_c, tverts, counts)
+        col4row = ops.loss_assign(cost)
+        losses, dv, de, dd = ops.loss_terms_assigned(verts, exist_c, edge.contiguous(), tverts, texist, tlabel,
+                                                     col4row, counts, weights)
+        ctx.save_for_backward(dv, de, dd)
+        ctx.mark_non_differentiable(losses)
+        return losses[3].clone(), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        dv, de, dd = ctx.saved_tensors
+        return (dv * g_total, de * g_total, dd * g_total, None, None, None, None, None)
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, exist, edge, tverts, texist, tlabel, m_pred, m_tgt, m_off, n_match, weights):
@@ -30,8 +50,13 @@ class _LossFn(torch.autograd.Function):
 
 
 class WireframeLoss(nn.Module):
-    def __init__(self, vertex_weight=1.0, edge_weight=1.0, existence_weight=1.0):
+    def __init__(self, vertex_weight=1.0, edge_weight=1.0, existence_weight=1.0, assignment="device"):
+        """assignment: "device" (default) = Hungarian matching on the GPU, no host sync at all;
+        "scipy" = the reference's scipy.optimize.linear_sum_assignment on the host (one sync)."""
         super().__init__()
+        if assignment not in ("device", "scipy"):
+            raise ValueError("assignment must be 'device' or 'scipy'")
+        self.assignment = assignment
         self.vertex_weight = vertex_weight
         self.edge_weight = edge_weight
         self.existence_weight = existence_weight
@@ -61,6 +86,14 @@ class WireframeLoss(nn.Module):
         pe = predictions["existence_probabilities"]
         pp = predictions["edge_probs"]
         dev = pv.device
+        if self.assignment == "device":
+            counts = targets["vertex_counts"].to(device=dev, dtype=torch.int64).contiguous()
+            tv = targets["vertices"].to(device=dev, dtype=torch.float32).contiguous()
+            te = targets["vertex_existence"].to(device=dev, dtype=torch.float32).contiguous()
+            tl = targets["edge_labels"].to(device=dev, dtype=torch.float32).contiguous()
+            w = (self.vertex_weight, self.existence_weight, self.edge_weight)
+            total, parts = _LossDevFn.apply(pv, pe, pp, tv, te, tl, counts, w)
+            return {"total_loss": total, "vertex_loss": parts[0], "existence_loss": parts[1], "edge_loss": parts[2]}
         matches = self._hungarian_matching(predictions, targets)
         lens = [len(m[0]) for m in matches]
         off = np.zeros(len(lens) + 1, dtype=np.int32)

@@ -81,6 +81,11 @@ SIGNATURES = {
     "wf3d_edge_prob_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_loss_cost_matrix": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                       c_int, c_void_p, c_void_p]),
+    "wf3d_loss_assign": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_loss_terms_assigned": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p,
+                                         c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
+                                         c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_void_p]),
     "wf3d_loss_terms": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                 c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

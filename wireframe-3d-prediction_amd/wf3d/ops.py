@@ -498,3 +498,31 @@ def loss_terms(verts, exist, edge, tverts, texist, tlabel, m_pred, m_tgt, m_off,
                                       _p(dverts), _p(dexist), _p(dedge), _p(losses), _p(ws), ws.numel(), _stream()),
           "loss_terms")
     return losses, dverts, dexist, dedge
+
+
+def loss_assign(cost):
+    """cost [B,V,V] -> col4row int32 [B,V]: optimal assignment per sample, computed on the device."""
+    _need_cuda(cost)
+    B, V, _ = cost.shape
+    out = torch.empty(B, V, dtype=torch.int32, device=cost.device)
+    check(_lib.load().wf3d_loss_assign(_p(cost), B, V, _p(out), _stream()), "loss_assign")
+    return out
+
+
+def loss_terms_assigned(verts, exist, edge, tverts, texist, tlabel, col4row, counts, weights):
+    _need_cuda(verts, exist, edge, tverts, texist, tlabel, col4row, counts)
+    B, V, _ = verts.shape
+    Ep = edge.shape[1] if edge is not None else 0
+    Et = tlabel.shape[1] if tlabel is not None else 0
+    dev = verts.device
+    dverts = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dexist = torch.empty(B, V, dtype=torch.float32, device=dev)
+    dedge = torch.empty(B, Ep, dtype=torch.float32, device=dev)
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    ws = scratch(B * 3 * 4, dev)
+    check(_lib.load().wf3d_loss_terms_assigned(_p(verts), verts.stride(0), verts.stride(1), _p(exist), _p(edge), Ep,
+                                               _p(tverts), tverts.shape[1], _p(texist), _p(tlabel), Et, _p(col4row),
+                                               _p(counts), B, V, float(weights[0]), float(weights[1]), float(weights[2]),
+                                               _p(dverts), _p(dexist), _p(dedge), _p(losses), _p(ws), ws.numel(),
+                                               _stream()), "loss_terms_assigned")
+    return losses, dverts, dexist, dedge
