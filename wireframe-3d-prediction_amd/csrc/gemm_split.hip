@@ -22,6 +22,10 @@
 #define WF3D_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no LDS fragment reads
 #endif
 
+#ifndef WF3D_DMA_SCHED
+#define WF3D_DMA_SCHED 0   // 256x256 kernel: 0 = DMA pieces spread over the slice, 1 = over its first half, 2 = bunched at the top
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -40,6 +44,16 @@ struct SplitParams {
 __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// The same instruction issued from inline asm.  The compiler models the builtin as a FLAT access
+// that may touch LDS and from then on turns every LDS wait into `s_waitcnt lgkmcnt(0)`, which
+// drains the fragment reads just issued for LATER MFMA groups; hidden in asm, the ds_read
+// bookkeeping stays exact (counted lgkmcnt) and the DMA is tracked by our own vmcnt waits.
+__device__ __forceinline__ void dma16_asm(const float* src, float* lds_wave_base) {
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds) : "memory");      // m0 is reserved: the compiler never keeps a value in it across statements
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_split_dma_kernel(const SplitParams p) {
@@ -557,6 +571,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma256_kernel(const SplitPa
         const int kn = (kt + 1) * SBK;
         const float* As = smem + stage * T4_STAGE;
         const float* Bs = As + T4_A;
+#if WF3D_DMA_SCHED == 2
+        if (ahead) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dma16(asrc[q] + kn, dA + q * 8 * SBK);
+                dma16(bsrc[q] + kn, dB + q * 8 * SBK);
+            }
+        }
+#endif
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int phi = ((2 * (2 * s2 + h)) ^ fsw) * 4, plo = phi ^ 4;
@@ -580,10 +603,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma256_kernel(const SplitPa
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#if WF3D_DMA_SCHED == 0
                     if (j == 0) {          // one DMA piece after every 6 MFMAs: 4 pieces per k16 step, 8 per slice
                         const int piece = s2 * 4 + i;
+#else
+                    if (s2 == 0) {         // one DMA piece after every 3 MFMAs of the FIRST k16 step
+                        const int piece = i * 2 + j;
+#endif
                         __builtin_amdgcn_sched_barrier(0);
-                        if (ahead) {
+                        if (ahead && WF3D_DMA_SCHED != 2) {
                             if (piece < 4) dma16(asrc[piece & 3] + kn, dA + (piece & 3) * 8 * SBK);
                             else           dma16(bsrc[piece & 3] + kn, dB + (piece & 3) * 8 * SBK);
                         }
@@ -624,6 +652,320 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma256_kernel(const SplitPa
     }
 }
 
+// ---------------------------------------------------------------------------
+// 256x256 tile, FOUR LDS stages of one k16 step each (64-B row slices, 32 KB per stage) and
+// register-pipelined fragments.  The two-stage kernel above starts every k16 step with a
+// burst of 12 ds_read_b128 per wave whose latency nothing covers: the barrier has just put
+// all eight waves in the same phase, so both waves of a SIMD wait together (PMC: MFMA pipe
+// busy 55 %).  Here the fragment reads run two MFMA groups (12 MFMAs) ahead of their use,
+// ACROSS step boundaries: the barrier at the top of step s publishes slice s+1 (not s), so
+// the reads of slice s+1's first fragments are issued while slice s is still being
+// multiplied, and after a barrier the next MFMA's operands are already in registers.
+//   step s:  s_waitcnt vmcnt(4)  (own DMA pieces of slice s+1 landed; s+2's stay in flight)
+//            s_barrier           (slice s+1 visible; stage (s-1)%4 free)
+//            4 groups i=0..3:  reads A(i+2) [or A(i-2) of slice s+1], B half of slice s+1,
+//                              one DMA piece of slice s+3, 6 MFMAs (A tile i x 2 B tiles x 3)
+// LDS image per operand and stage: [256 rows][64 B], chunk' = chunk ^ ((row >> 2) & 3): the
+// 16 lanes of a ds_read_b128 group (16 rows, same chunk) hit 16 distinct 16-B slots.
+// ---------------------------------------------------------------------------
+constexpr int P4_ROWF = 16, P4_T = 256 * P4_ROWF, P4_STAGE = 2 * P4_T;
+
+struct P4Frags {
+    f32x4 ah[4], al[4];          // A tile i of the current (or next) step, slot = i
+    f32x4 bh[2][2], bl[2][2];    // [buffer = step parity][B tile j]
+};
+
+template <int PAR>
+__device__ __forceinline__ void p4_step(f32x16 (&acc)[4][2], P4Frags& f, float* smem, int s, int s1, int a_hi, int a_lo,
+                                        int b_hi, int b_lo, const float* const (&asrc)[2], const float* const (&bsrc)[2],
+                                        int wave) {
+    const float* cur = smem + (s & 3) * P4_STAGE;
+    const float* nxt = smem + ((s + 1) & 3) * P4_STAGE;
+    float* dst = smem + ((s + 3) & 3) * P4_STAGE + wave * 2 * 16 * P4_ROWF;
+    // Branch-free body (one basic block keeps the compiler's lgkmcnt bookkeeping exact): past the
+    // end the DMA re-fetches the last slice into a stage nobody reads again, so there are always
+    // exactly 4 younger pieces in flight at the wait below.
+    const int kn = min(s + 3, s1 - 1) * P4_ROWF;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        {   // A fragments two groups ahead
+            const int t = (i + 2) & 3;
+            const float* base = (i < 2 ? cur : nxt) + t * (32 * P4_ROWF);
+            f.ah[t] = *reinterpret_cast<const f32x4*>(base + a_hi);
+            f.al[t] = *reinterpret_cast<const f32x4*>(base + a_lo);
+        }
+        if (i < 2) {   // B fragments of the next step, one tile per group
+            const float* base = nxt + P4_T + i * (32 * P4_ROWF);
+            f.bh[PAR ^ 1][i] = *reinterpret_cast<const f32x4*>(base + b_hi);
+            f.bl[PAR ^ 1][i] = *reinterpret_cast<const f32x4*>(base + b_lo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 2) dma16_asm(asrc[i & 1] + kn, dst + (i & 1) * 16 * P4_ROWF);
+        else       dma16_asm(bsrc[i & 1] + kn, dst + P4_T + (i & 1) * 16 * P4_ROWF);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, f.ah[i]), al = __builtin_bit_cast(bf16x8, f.al[i]);
+        const bf16x8 bh0 = __builtin_bit_cast(bf16x8, f.bh[PAR][0]), bl0 = __builtin_bit_cast(bf16x8, f.bl[PAR][0]);
+        const bf16x8 bh1 = __builtin_bit_cast(bf16x8, f.bh[PAR][1]), bl1 = __builtin_bit_cast(bf16x8, f.bl[PAR][1]);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[i][1], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[i][1], 0, 0, 0);
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[i][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_split_p4_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * P4_STAGE];      // 131,072 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows wm*128, cols wn*64
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 256;
+    const int ktotal = p.K / SBK;
+    const int s0 = blockIdx.z * p.kt_per_split * 2;                       // k16 steps
+    const int s1 = min(ktotal, (int)(blockIdx.z + 1) * p.kt_per_split) * 2;
+
+    // DMA: one instruction = 16 rows x 64 B; wave w stages rows 32w .. 32w+31 of A and of B
+    const float* asrc[2];
+    const float* bsrc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        const int chunk = ((lane & 3) ^ ((row >> 2) & 3)) * 4;
+        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
+        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
+    }
+    auto issue = [&](int s) {
+        float* dst = smem + (s & 3) * P4_STAGE + wave * 2 * 16 * P4_ROWF;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16_asm(asrc[q] + s * P4_ROWF, dst + q * 16 * P4_ROWF);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dma16_asm(bsrc[q] + s * P4_ROWF, dst + P4_T + q * 16 * P4_ROWF);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment offsets (floats) inside an operand's stage image
+    const int fsw = (l31 >> 2) & 3;
+    const int c_hi = ((2 * h) ^ fsw) * 4, c_lo = ((2 * h + 1) ^ fsw) * 4;
+    const int a_row = (wm * 128 + l31) * P4_ROWF, b_row = (wn * 64 + l31) * P4_ROWF;
+    const int a_hi = a_row + c_hi, a_lo = a_row + c_lo, b_hi = b_row + c_hi, b_lo = b_row + c_lo;
+
+    // prologue: slices s0, s0+1, s0+2 in flight; slice s0 published; first fragments requested
+    const int nsteps = s1 - s0;                                           // even, >= 2
+    issue(s0);
+    issue(s0 + 1);
+    issue(min(s0 + 2, s1 - 1));
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    P4Frags f;
+    {
+        const float* cur = smem + (s0 & 3) * P4_STAGE;
+        const int par = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f.bh[par][j] = *reinterpret_cast<const f32x4*>(cur + P4_T + j * (32 * P4_ROWF) + b_hi);
+            f.bl[par][j] = *reinterpret_cast<const f32x4*>(cur + P4_T + j * (32 * P4_ROWF) + b_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const f32x4*>(cur + i * (32 * P4_ROWF) + a_hi);
+            f.al[i] = *reinterpret_cast<const f32x4*>(cur + i * (32 * P4_ROWF) + a_lo);
+        }
+    }
+    // The stage ring is indexed by the absolute step number; the DMA sources by the same.
+    for (int s = s0; s < s1; s += 2) {
+        p4_step<0>(acc, f, smem, s, s1, a_hi, a_lo, b_hi, b_lo, asrc, bsrc, wave);
+        p4_step<1>(acc, f, smem, s + 1, s1, a_hi, a_lo, b_hi, b_lo, asrc, bsrc, wave);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
+
+    const bool split = p.ksplit > 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + (wn * 2 + j) * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wm * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (split) {
+                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v += bv;
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 256x256x32 tile on v_mfma_f32_16x16x32_bf16.  Same LDS image, DMA and two stages as the
+// 256x256 kernel above, different MFMA shape: in an MFMA-dense loop on real data this chip is
+// clock-limited by power (scripts/micro/mfma_peak.hip, register-only, random operands: the
+// 32x32x16 loop holds 1.89 PF, the 16x16x32 loop 2.06-2.21 PF at equal cycles per FLOP), so the
+// shape that costs less energy per FLOP wins.  LDS bytes per FLOP are unchanged (128x64 per
+// wave).  Each wave: 8 x 4 accumulator tiles of 16x16; per k32 slice 8 B reads up front, the
+// A reads rolling one row-tile (12 MFMAs) ahead.  The MFMA takes the B fragment as its first
+// operand, so a lane ends up with 4 consecutive columns of one output row: 16-B stores.
+// Lane (r = lane & 15, g = lane >> 4) reads row r, chunks 2g (hi) / 2g+1 (lo); the swizzle that
+// makes ds_read_b128's lane groups conflict-free for this pattern is swz16() below.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int swz16(int row) {
+    const int q = (row >> 1) & 7;
+    return q ^ ((((q >> 1) ^ (q >> 2)) & 1) << 1);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * T4_STAGE];      // 131,072 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows wm*128, cols wn*64
+    const int r16 = lane & 15, g = lane >> 4;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 256;
+    const int ktotal = p.K / SBK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    const float* asrc[4];
+    const float* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = ((lane & 7) ^ swz16(row)) * 4;
+        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
+        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fs = swz16(r16);
+    const int c_hi = ((2 * g) ^ fs) * 4, c_lo = ((2 * g + 1) ^ fs) * 4;
+    const int a_row = (wm * 128 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
+
+    {
+        float* dA = smem + wave * 4 * 8 * SBK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dma16_asm(asrc[q] + kt0 * SBK, dA + q * 8 * SBK);
+            dma16_asm(bsrc[q] + kt0 * SBK, dA + T4_A + q * 8 * SBK);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        float* dA = smem + (stage ^ 1) * T4_STAGE + wave * 4 * 8 * SBK;
+        float* dB = dA + T4_A;
+        // branch-free: the last iteration re-fetches its own slice into the idle stage
+        const int kn = min(kt + 1, kt1 - 1) * SBK;
+        const float* As = smem + stage * T4_STAGE + a_row;
+        const float* Bs = smem + stage * T4_STAGE + T4_A + b_row;
+        f32x4 bh[4], bl[4], ah, al, ahn, aln;
+        al = *reinterpret_cast<const f32x4*>(As + c_lo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bh[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_hi);
+        ah = *reinterpret_cast<const f32x4*>(As + c_hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_lo);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < 7) {
+                ahn = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_hi);
+                aln = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_lo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 4) {          // all 8 DMA pieces of the next slice within the first half of this one
+                if (i < 2) { dma16_asm(asrc[2 * i] + kn, dA + (2 * i) * 8 * SBK);     dma16_asm(asrc[2 * i + 1] + kn, dA + (2 * i + 1) * 8 * SBK); }
+                else       { dma16_asm(bsrc[2 * i - 4] + kn, dB + (2 * i - 4) * 8 * SBK); dma16_asm(bsrc[2 * i - 3] + kn, dB + (2 * i - 3) * 8 * SBK); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), val, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), vah, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ah = ahn; al = aln;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage ^= 1;
+    }
+
+    const bool split = p.ksplit > 1;
+    const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + g * 4;
+        if (col >= p.N) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (!split && p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = col + e < p.N ? p.bias[col + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wm * 128 + i * 16 + r16;
+            if (row >= p.M) continue;
+            f32x4 v = acc[i][j];
+            float* c = split ? p.slab + ((size_t)blockIdx.z * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
+            if (!split) v += bv;
+            if (WF3D_ABLATE == 3 && v[0] != 1234.5f) continue;       // timing-only: no C stores
+            if (vec && col + 3 < p.N) {
+                if (!split && p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+                *reinterpret_cast<f32x4*>(c) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= p.N) break;
+                    float o = v[e];
+                    if (!split && p.accumulate) o += c[e];
+                    c[e] = o;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
     const size_t total = (size_t)p.M * p.N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -638,17 +980,19 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) 
 }
 
 // Kernel choice.  WF3D_SPLIT_DMA forces one: 2 = 128x128 2-stage, 3 = 256x128 3-stage,
-// 4 = 256x256 2-stage.  Default (unset): 256x256 when the output has >= 512 such tiles (the
-// tall forward / dgrad GEMMs: +4 %), else 256x128 (wgrad: few tiles, long split-K reductions).
+// 4 = 256x256 2-stage (32x32x16 MFMA), 5 = 256x256 4-stage k16 register-pipelined, 6 = 256x256
+// 2-stage on 16x16x32 MFMA.  Default (unset): 6 when the output has >= 512 such tiles (the tall
+// forward / dgrad GEMMs), else 3 (few tiles, long split-K reductions).  Measured on the encoder
+// shapes, same process: 6 is 11-14 % faster than 4; 5 equals 4 with its DMA issued early (+5 %).
 int split_variant(int M, int N) {
     static const int forced = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 4) return forced;
-    return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= 512 ? 4 : 3;
+    if (forced >= 2 && forced <= 6) return forced;
+    return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= 512 ? 6 : 3;
 }
 
 void plan(int M, int N, int K, int& ksplit, int& kt_per) {
     const int v = split_variant(M, N);
-    const int bm = v >= 3 ? 256 : 128, bn = v == 4 ? 256 : 128;
+    const int bm = v >= 3 ? 256 : 128, bn = v >= 4 ? 256 : 128;
     const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, bn);
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
@@ -688,13 +1032,15 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
     const int variant = split_variant(M, N);
     const bool deep = variant == 3;
-    p.nbm = wf3d_cdiv(M, variant >= 3 ? 256 : 128); p.nbn = wf3d_cdiv(N, variant == 4 ? 256 : 128);
+    p.nbm = wf3d_cdiv(M, variant >= 3 ? 256 : 128); p.nbn = wf3d_cdiv(N, variant >= 4 ? 256 : 128);
     plan(M, N, K, p.ksplit, p.kt_per_split);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    if (variant == 6) hipLaunchKernelGGL(gemm_split_x16_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    else if (variant == 5) hipLaunchKernelGGL(gemm_split_p4_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    else if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else      hipLaunchKernelGGL(gemm_split_dma_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
     WF3D_LAUNCH_CHECK();
