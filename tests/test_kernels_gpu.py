@@ -359,7 +359,8 @@ def test_split_transpose_and_wgrad_form(ops, act, R, C):
     assert rel(dW, G.double().cpu().T @ want) < TOL_SPLIT
 
 
-@pytest.mark.parametrize("K,Mo,No", [(32, 256, 128), (64, 256, 128), (4096, 512, 256), (1024, 256, 384), (131072, 256, 128)])
+@pytest.mark.parametrize("K,Mo,No", [(32, 256, 128), (64, 256, 128), (4096, 512, 256), (1024, 256, 384), (131072, 256, 128),
+                                     (32, 256, 256), (96, 512, 256), (4000 * 32 // 32 * 32 // 125, 256, 512), (65536, 512, 256)])
 def test_gemm_split_tn_matches_transposed_nt_path(ops, K, Mo, No):
     """wgrad on reduction-major operands (transposing LDS reads) == the NT kernel on materialised
     transposes, and == fp64 within the split tolerance."""

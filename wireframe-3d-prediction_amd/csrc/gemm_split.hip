@@ -839,7 +839,23 @@ __device__ __forceinline__ int swz16(int row) {
     const int q = (row >> 1) & 7;
     return q ^ ((((q >> 1) ^ (q >> 2)) & 1) << 1);
 }
+// TN form: chunk swizzle per k-row of the [32 k][256 cols] image.  A half-wave of a
+// ds_read_b64_tr_b16 touches k-rows {t, 8+t : t = 0..3} (+4 for the second read) and two
+// chunks that differ in bit 1, so f uses bits 0, 2, 3: 16 distinct 16-B slots per half-wave.
+__device__ __forceinline__ int swz_tn16(int k) { return (k & 1) | ((k & 2) << 1) | (k & 8); }
 
+__device__ __forceinline__ f32x4 tr_frag16(const char* base, int off) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off + 4 * 1024));
+    return __builtin_bit_cast(f32x4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// TN = false:  C[M,N] (+)= A·B^T,  A = sx8[M,K], B = sx8[N,K]   (forward, dgrad)
+// TN = true :  C[M,N] (+)= A^T·B,  A = sx8[K,M], B = sx8[K,N]   (wgrad, operands as stored; M, N % 256 == 0):
+//              the LDS image is [32 k-rows][256 cols] per operand and the fragments come out of
+//              ds_read_b64_tr_b16: the 16 lanes of k-group g read the 4 x 16 block of k-rows 8g..8g+3
+//              (then 8g+4..8g+7) and each receives its column's 4 k-values — exactly the 16x16x32 operand.
+template <bool TN>
 __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * T4_STAGE];      // 131,072 B
     const int tid = threadIdx.x, lane = tid & 63;
@@ -856,15 +872,25 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
     const int kt0 = blockIdx.z * p.kt_per_split;
     const int kt1 = min(ktotal, kt0 + p.kt_per_split);
 
+    // DMA sources: 4 A pieces + 4 B pieces of 1 KB per wave and slice.  NT: a piece = 8 tile rows x 128 B;
+    // TN: a piece = one k-row of the tile (256 cols x 4 B).  Either way piece q lands at wave*1024 + q*256 floats.
     const float* asrc[4];
     const float* bsrc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + (lane >> 3);
-        const int chunk = ((lane & 7) ^ swz16(row)) * 4;
-        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
-        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
+        if (TN) {
+            const int kr = wave * 4 + q;
+            const int chunk = (lane ^ swz_tn16(kr)) * 4;
+            asrc[q] = p.A + (size_t)kr * p.lda + m0 + chunk;
+            bsrc[q] = p.B + (size_t)kr * p.ldb + n0 + chunk;
+        } else {
+            const int row = (wave * 4 + q) * 8 + (lane >> 3);
+            const int chunk = ((lane & 7) ^ swz16(row)) * 4;
+            asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
+            bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
+        }
     }
+    const size_t astep = TN ? (size_t)SBK * p.lda : SBK, bstep = TN ? (size_t)SBK * p.ldb : SBK;   // floats per slice
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -872,16 +898,25 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // fragment addressing.  NT: float offsets of the hi / lo chunk of row r16 (tile i adds 16 rows).
     const int fs = swz16(r16);
     const int c_hi = ((2 * g) ^ fs) * 4, c_lo = ((2 * g + 1) ^ fs) * 4;
     const int a_row = (wm * 128 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
+    // TN: byte offsets of the hi chunk piece lane (g, tq, tp) addresses for tile i / j (lo = offset ^ 16)
+    const int tq = r16 >> 2, tp = r16 & 3;
+    const int ftn = swz_tn16(8 * g + tq);
+    int a_tn[8], b_tn[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_tn[i] = (8 * g + tq) * 1024 + ((2 * (wm * 16 + 2 * i + (tp >> 1))) ^ ftn) * 16 + (tp & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_tn[j] = (8 * g + tq) * 1024 + ((2 * (wn * 8 + 2 * j + (tp >> 1))) ^ ftn) * 16 + (tp & 1) * 8;
 
     {
         float* dA = smem + wave * 4 * 8 * SBK;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            dma16_asm(asrc[q] + kt0 * SBK, dA + q * 8 * SBK);
-            dma16_asm(bsrc[q] + kt0 * SBK, dA + T4_A + q * 8 * SBK);
+            dma16_asm(asrc[q] + kt0 * astep, dA + q * 8 * SBK);
+            dma16_asm(bsrc[q] + kt0 * bstep, dA + T4_A + q * 8 * SBK);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -893,26 +928,37 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
         float* dA = smem + (stage ^ 1) * T4_STAGE + wave * 4 * 8 * SBK;
         float* dB = dA + T4_A;
         // branch-free: the last iteration re-fetches its own slice into the idle stage
-        const int kn = min(kt + 1, kt1 - 1) * SBK;
-        const float* As = smem + stage * T4_STAGE + a_row;
-        const float* Bs = smem + stage * T4_STAGE + T4_A + b_row;
+        const size_t kn = (size_t)min(kt + 1, kt1 - 1);
+        const size_t ka = kn * astep, kb = kn * bstep;
+        const float* As = smem + stage * T4_STAGE;
+        const float* Bs = As + T4_A;
+        const char* Ac = reinterpret_cast<const char*>(As);
+        const char* Bc = reinterpret_cast<const char*>(Bs);
+        auto rdA = [&](int i, bool lo) -> f32x4 {
+            if (TN) return tr_frag16(Ac, lo ? (a_tn[i] ^ 16) : a_tn[i]);
+            return *reinterpret_cast<const f32x4*>(As + a_row + i * 16 * SBK + (lo ? c_lo : c_hi));
+        };
+        auto rdB = [&](int j, bool lo) -> f32x4 {
+            if (TN) return tr_frag16(Bc, lo ? (b_tn[j] ^ 16) : b_tn[j]);
+            return *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + (lo ? c_lo : c_hi));
+        };
         f32x4 bh[4], bl[4], ah, al, ahn, aln;
-        al = *reinterpret_cast<const f32x4*>(As + c_lo);
+        al = rdA(0, true);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bh[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_hi);
-        ah = *reinterpret_cast<const f32x4*>(As + c_hi);
+        for (int j = 0; j < 4; ++j) bh[j] = rdB(j, false);
+        ah = rdA(0, false);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_lo);
+        for (int j = 0; j < 4; ++j) bl[j] = rdB(j, true);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i < 7) {
-                ahn = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_hi);
-                aln = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_lo);
+                ahn = rdA(i + 1, false);
+                aln = rdA(i + 1, true);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (i < 4) {          // all 8 DMA pieces of the next slice within the first half of this one
-                if (i < 2) { dma16_asm(asrc[2 * i] + kn, dA + (2 * i) * 8 * SBK);     dma16_asm(asrc[2 * i + 1] + kn, dA + (2 * i + 1) * 8 * SBK); }
-                else       { dma16_asm(bsrc[2 * i - 4] + kn, dB + (2 * i - 4) * 8 * SBK); dma16_asm(bsrc[2 * i - 3] + kn, dB + (2 * i - 3) * 8 * SBK); }
+                if (i < 2) { dma16_asm(asrc[2 * i] + ka, dA + (2 * i) * 8 * SBK);         dma16_asm(asrc[2 * i + 1] + ka, dA + (2 * i + 1) * 8 * SBK); }
+                else       { dma16_asm(bsrc[2 * i - 4] + kb, dB + (2 * i - 4) * 8 * SBK); dma16_asm(bsrc[2 * i - 3] + kb, dB + (2 * i - 3) * 8 * SBK); }
             }
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
@@ -1038,7 +1084,7 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 6) hipLaunchKernelGGL(gemm_split_x16_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    if (variant == 6) hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (variant == 5) hipLaunchKernelGGL(gemm_split_p4_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
@@ -1060,12 +1106,20 @@ extern "C" int wf3d_gemm_split_tn_ok(int Mo, int No, int K, int lda, int ldb) {
 }
 
 namespace {
+// Wgrad kernel choice: 256x256 tiles on the 16x16x32 MFMA when the output allows (WF3D_TN16=0 forces
+// the 256x128 32x32x16 kernel).
+bool tn16(int Mo, int No) {
+    static const int off = [] { const char* e = getenv("WF3D_TN16"); return e && atoi(e) == 0; }();
+    return !off && Mo % 256 == 0 && No % 256 == 0;
+}
 void plan_tn(int Mo, int No, int K, int& ksplit, int& kt_per) {
-    const long tiles = (long)(Mo / 256) * (No / 128);
+    const bool big = tn16(Mo, No);
+    const long tiles = (long)(Mo / 256) * (No / (big ? 256 : 128));
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
     if (tiles >= 256 || ktotal < 8) return;
-    int want = (int)((512 + tiles - 1) / tiles);
+    // one workgroup per CU either way; the big tile runs one full wave of 256 workgroups
+    int want = (int)(((big ? 256 : 512) + tiles - 1) / tiles);
     int ks = want < ktotal / 4 ? want : ktotal / 4;
     if (ks > 64) ks = 64;
     if (ks < 2) return;
@@ -1091,13 +1145,15 @@ extern "C" int wf3d_gemm_split_tn(const void* A_sx8, const void* B_sx8, float* C
     SplitParams p{};
     p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = nullptr;
     p.M = Mo; p.N = No; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
-    p.nbm = Mo / 256; p.nbn = No / 128;
+    const bool big = tn16(Mo, No);
+    p.nbm = Mo / 256; p.nbn = No / (big ? 256 : 128);
     plan_tn(Mo, No, K, p.ksplit, p.kt_per_split);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * Mo * No * sizeof(float) : 0;
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_split_tn_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    if (big) hipLaunchKernelGGL(gemm_split_x16_kernel<true>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    else     hipLaunchKernelGGL(gemm_split_tn_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const size_t total = (size_t)Mo * No;
