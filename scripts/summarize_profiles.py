@@ -68,7 +68,7 @@ fetch, write, sq = pmc(f"prof_{tag}_fetch/**/*_counter_collection.csv"), \
     pmc(f"prof_{tag}_write/**/*_counter_collection.csv"), pmc(f"prof_{tag}_sq/**/*_counter_collection.csv")
 
 BIG_US = 300.0          # the encoder's twelve >=137-GFLOP GEMM launches per step all run > 0.35 ms
-DOM = os.environ.get("WF3D_DOMINANT", "gemm_split_dma3_kernel")   # dominant kernel (fp32 mode: "gemm_kernel<2, 2, 2, 2")
+DOM = os.environ.get("WF3D_DOMINANT", "gemm_split_x16_kernel<false>")   # dominant kernel (fp32 mode: "gemm_kernel<2, 2, 2, 2")
 
 
 def big(vals):
@@ -91,7 +91,7 @@ for name in sorted(set(fetch) | set(write)):
         gemm_write += big(wv)
 mfma = {}
 for name, ctrs in sq.items():
-    if not name.startswith(DOM):
+    if not (name.startswith(DOM) or name.startswith("gemm_split_x16_kernel")):
         continue
     busy = sum(v for v, d, _ in ctrs.get("SQ_VALU_MFMA_BUSY_CYCLES", []) if d >= BIG_US)
     gui = sum(v for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []) if d >= BIG_US)
@@ -99,11 +99,14 @@ for name, ctrs in sq.items():
     sqb = sum(v for v, d, _ in ctrs.get("SQ_BUSY_CYCLES", []) if d >= BIG_US)
     mops = sum(v for v, d, _ in ctrs.get("SQ_INSTS_VALU_MFMA_MOPS_F32", []) if d >= BIG_US)
     n = len([1 for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []) if d >= BIG_US])
+    dur_us = sum(d for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []) if d >= BIG_US)
     if n:
         mfma[name] = {"launches": n, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui, "SQ_WAVE_CYCLES": waves,
                       "SQ_BUSY_CYCLES": sqb, "SQ_INSTS_VALU_MFMA_MOPS_F32": mops,
                       # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA_BUSY over all 1024 SIMDs' pipes
-                      "mfma_busy_frac": busy / (gui / 8.0 * 1024.0) if gui else None}
+                      "mfma_busy_frac": busy / (gui / 8.0 * 1024.0) if gui else None,
+                      # effective clock under load (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE / 8 / wall
+                      "effective_clock_ghz": gui / 8.0 / (dur_us * 1e3) if dur_us else None}
 summary["gemm_mfma"] = mfma
 if gemm_fetch and gemm_write:
     rd = 2 * 1024 * sum(gemm_fetch) / len(gemm_fetch)
@@ -130,5 +133,6 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
     if mfma:
         f.write("\n## MFMA pipe occupancy of the dominant kernel (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))\n\n")
         for n, e in mfma.items():
-            f.write(f"* `{n}`: {e['launches']} launches, busy fraction {e['mfma_busy_frac']:.3f}\n")
+            f.write(f"* `{n}`: {e['launches']} launches, busy fraction {e['mfma_busy_frac']:.3f}, effective clock "
+                    f"{e['effective_clock_ghz']:.2f} GHz (GRBM_GUI_ACTIVE / 8 / wall)\n")
 print(open(os.path.join(P, f"{tag}_summary.md")).read())

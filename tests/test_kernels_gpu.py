@@ -359,6 +359,23 @@ def test_split_transpose_and_wgrad_form(ops, act, R, C):
     assert rel(dW, G.double().cpu().T @ want) < TOL_SPLIT
 
 
+@pytest.mark.parametrize("K", [32, 96, 512])
+def test_gemm_split_tall_exact_on_integer_data(ops, K):
+    """>= 512 tiles of 256x256: the 16x16x32-MFMA kernel at the encoder's launch shape.  Integer data makes every
+    fp32 sum exact whatever the order, so any slice counted twice / dropped / mis-addressed shows up bit-exactly."""
+    M, N = 32768, 1024
+    A = (torch.arange(M * K, device=dev()).reshape(M, K) % 11 - 5).float()
+    B = ((torch.arange(N * K, device=dev()).reshape(N, K) * 7) % 13 - 6).float()
+    bias = (torch.arange(N, device=dev()) % 5 - 2).float()
+    got = ops.gemm_split(ops.split_rows(A), ops.split_rows(B), bias=bias)
+    want = A.double() @ B.double().T + bias.double()
+    assert torch.equal(got.double(), want)
+    # random data, same launch shape: within the split tolerance of fp64
+    Ar, Br = rnd(M, K, seed=11), rnd(N, K, seed=12)
+    gr = ops.gemm_split(ops.split_rows(Ar), ops.split_rows(Br))
+    assert rel(gr[::37], (Ar[::37].double() @ Br.double().T).cpu()) < TOL_SPLIT
+
+
 @pytest.mark.parametrize("K,Mo,No", [(32, 256, 128), (64, 256, 128), (4096, 512, 256), (1024, 256, 384), (131072, 256, 128),
                                      (32, 256, 256), (96, 512, 256), (4000 * 32 // 32 * 32 // 125, 256, 512), (65536, 512, 256)])
 def test_gemm_split_tn_matches_transposed_nt_path(ops, K, Mo, No):

@@ -979,22 +979,29 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 
     const bool split = p.ksplit > 1;
     const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
+    // lane holds C[row = .. + r16][4 consecutive columns] of each (i, j) tile.  Row-tile outer, column-tile
+    // inner: the two 64-B halves of every 128-B line of C leave in back-to-back stores.
+    const int colw = n0 + wn * 64 + g * 4;
+    f32x4 bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + g * 4;
-        if (col >= p.N) continue;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!split && p.bias) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = col + e < p.N ? p.bias[col + e] : 0.f;
+            for (int e = 0; e < 4; ++e) bv[j][e] = colw + j * 16 + e < p.N ? p.bias[colw + j * 16 + e] : 0.f;
         }
+    }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = m0 + wm * 128 + i * 16 + r16;
-            if (row >= p.M) continue;
+    for (int i = 0; i < 8; ++i) {
+        const int row = m0 + wm * 128 + i * 16 + r16;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = colw + j * 16;
+            if (col >= p.N) continue;
             f32x4 v = acc[i][j];
             float* c = split ? p.slab + ((size_t)blockIdx.z * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
-            if (!split) v += bv;
+            if (!split) v += bv[j];
             if (WF3D_ABLATE == 3 && v[0] != 1234.5f) continue;       // timing-only: no C stores
             if (vec && col + 3 < p.N) {
                 if (!split && p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
