@@ -174,6 +174,11 @@ int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N, int C, flo
 int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
                    const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
                    const float* dpf_direct, int B, int N, int C, float* dpf, void* stream);
+/* Same values written as the sx8 split operand of the output Linear's dgrad / wgrad GEMMs (C % 8 == 0):
+ * saves the fp32 round trip through wf3d_split_rows. */
+int wf3d_pool4_bwd_sx8(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
+                       const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                       const float* dpf_direct, int B, int N, int C, float* dpf_sx8, void* stream);
 
 /* ------------------------------------------------------------------------
  * Vertex head tail (VertexPredictor.py:118-127): existence = sigmoid(o[:,:,3]),

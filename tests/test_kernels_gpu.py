@@ -238,6 +238,17 @@ def test_pool4_fwd_bwd(ops, B, N, C):
     assert rel(dpf, pfc.grad) < TOL_ELT
     dpf2 = ops.pool4_bwd(valid, cnt, arg_m, arg_u, cot[0], cot[1], cot[2], cot[3], direct, B, N, C)
     assert rel(dpf2, pfc.grad + direct.cpu()) < TOL_ELT
+    # column sums from the [B, C] cotangents alone == column sums of the scattered tensor
+    for d, full in ((None, dpf), (direct, dpf2)):
+        cs = ops.pool4_bwd_colsum(valid, cnt, arg_m, arg_u, cot[0], cot[1], cot[2], cot[3], d, B, N, C)
+        assert rel(cs, full.double().sum((0, 1))) < 2e-5
+    if C % 8 == 0:
+        # sx8 output: hi + lo planes reproduce the fp32 result to the split format's 2^-17
+        for d, full in ((None, dpf), (direct, dpf2)):
+            s8 = ops.pool4_bwd(valid, cnt, arg_m, arg_u, cot[0], cot[1], cot[2], cot[3], d, B, N, C, sx8=True)
+            sh, sl = unpack_sx8(s8.view(B * N, C))
+            assert torch.equal(sh, full.view(B * N, C).bfloat16().float())
+            assert rel(sh + sl, full.view(B * N, C)) < 2e-5
 
 
 def test_cpu_tensors_rejected(ops):

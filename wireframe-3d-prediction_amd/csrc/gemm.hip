@@ -398,7 +398,10 @@ SplitPlan plan_split(int M, int N, int K, int bm, int bn) {
     if (tiles >= 256 || ktotal < 8) return s;
     int want = (int)((512 + tiles - 1) / tiles);
     int ks = want < ktotal / 4 ? want : ktotal / 4;
-    if (ks > 64) ks = 64;
+    // Few tiles and a very long reduction (first-layer wgrad: 512 x 8 outputs over K = B*N rows) stream
+    // their operands from HBM: they need >= 2 workgroups per CU in flight, slabs stay tiny.
+    const int cap = tiles <= 8 ? 256 : 64;
+    if (ks > cap) ks = cap;
     if (ks < 2) return s;
     s.kt_per = wf3d_cdiv(ktotal, ks);
     s.ksplit = wf3d_cdiv(ktotal, s.kt_per);      // no empty split

@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __rest
 // dpf written 16 B per lane: a thread owns 4 channels of one cloud (its 4 pooled cotangents and
 // 2 arg-max indices live in registers) and walks the points of its split; 256/(C/4) points of a
 // split are written per pass, each a contiguous C*4-byte row.
+// SX8: dpf is written as the next GEMMs' split operand (include/wf3d.h, sx8): of each group of 8 channels
+// the thread owning channels c..c+3 stores 4 bf16 high parts at byte (c & 7) * 2 of the group's first
+// 16 B and the 4 low parts at the same offset of its second 16 B.
+template <bool SX8>
 __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict__ valid, const float* __restrict__ cnt,
                                                          const int32_t* __restrict__ arg_m, const int32_t* __restrict__ arg_u,
                                                          const float* __restrict__ dmmax, const float* __restrict__ dmavg,
@@ -120,7 +124,19 @@ __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict_
             if (n == au[j]) g[j] += g_um[j];
         }
         if (dpf_direct) g += *reinterpret_cast<const f32x4*>(dpf_direct + idx);
-        *reinterpret_cast<f32x4*>(dpf + idx) = g;
+        if (SX8) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)g[j]; lo[j] = (__bf16)(g[j] - (float)hi[j]); }
+            float* grp = dpf + (idx & ~(size_t)7);
+            const int half = (c & 4) >> 1;                       // floats: 0 or 2 (= 8 bytes)
+            *reinterpret_cast<f32x2*>(grp + half) = __builtin_bit_cast(f32x2, hi);
+            *reinterpret_cast<f32x2*>(grp + 4 + half) = __builtin_bit_cast(f32x2, lo);
+        } else {
+            *reinterpret_cast<f32x4*>(dpf + idx) = g;
+        }
     }
 }
 
@@ -200,20 +216,39 @@ extern "C" int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N,
     return WF3D_OK;
 }
 
+static int pool4_bwd_impl(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
+                          const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                          const float* dpf_direct, int B, int N, int C, float* dpf, bool sx8, void* stream);
+
 extern "C" int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
                               const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
                               const float* dpf_direct, int B, int N, int C, float* dpf, void* stream) {
+    return pool4_bwd_impl(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C, dpf, false, stream);
+}
+
+extern "C" int wf3d_pool4_bwd_sx8(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
+                                  const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                                  const float* dpf_direct, int B, int N, int C, float* dpf_sx8, void* stream) {
+    return pool4_bwd_impl(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C, dpf_sx8, true, stream);
+}
+
+static int pool4_bwd_impl(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
+                          const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                          const float* dpf_direct, int B, int N, int C, float* dpf, bool sx8, void* stream) {
     WF3D_CHECK(B > 0 && N > 0 && C > 0 && B <= 65535, WF3D_ERR_ARG, "wf3d_pool4_bwd: bad dims");
     WF3D_CHECK(valid && cnt && arg_m && arg_u && dpf, WF3D_ERR_ARG, "wf3d_pool4_bwd: null pointer");
     const bool vec = C % 4 == 0 && ((uintptr_t)dpf % 16 == 0) && (!dpf_direct || (uintptr_t)dpf_direct % 16 == 0) &&
                      (C / 4 >= 256 || 256 % (C / 4) == 0);
+    WF3D_CHECK(!sx8 || (vec && C % 8 == 0), WF3D_ERR_UNSUPPORTED, "wf3d_pool4_bwd_sx8: needs C %% 8 == 0 and 16-B aligned tensors (C=%d)", C);
     if (vec) {
         int ns = 4096 / (B * wf3d_cdiv(C / 4, 256));
         const int cap = wf3d_cdiv(N, 16);
         ns = ns > cap ? cap : (ns < 1 ? 1 : ns);
         const int npb = wf3d_cdiv(N, ns);
-        hipLaunchKernelGGL(pool4_bwd_kernel, dim3(wf3d_cdiv(C / 4, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
-                           valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+        if (sx8) hipLaunchKernelGGL(pool4_bwd_kernel<true>, dim3(wf3d_cdiv(C / 4, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
+                                    valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+        else     hipLaunchKernelGGL(pool4_bwd_kernel<false>, dim3(wf3d_cdiv(C / 4, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
+                                    valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
     } else {
         const int ns = pool_nsplit(B, N, C);
         const int npb = wf3d_cdiv(N, ns);

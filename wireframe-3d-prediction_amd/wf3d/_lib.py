@@ -65,6 +65,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_pool4_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_pool4_bwd_sx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_edge_gather_verts": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p,

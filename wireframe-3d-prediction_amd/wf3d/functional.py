@@ -91,6 +91,8 @@ class EncoderFn(torch.autograd.Function):
         ctx.n_hidden, ctx.dims, ctx.split = n_hidden, (B, N, C), split
         ctx.params = params
         ctx.saved = (x2, valid, zs, stats, hs, arg_m, arg_u, cnt)
+        # unused outputs (point_features when only its pools are consumed) must not come back as 268 MB of zeros
+        ctx.set_materialize_grads(False)
         pf3 = pf.view(B, N, C)
         return pooled, pf3, umean, umax
 
@@ -109,8 +111,17 @@ class EncoderFn(torch.autograd.Function):
             dumean = dumean.contiguous()
         if dumax is not None:
             dumax = dumax.contiguous()
-        dz = ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C).view(M, C)
-        dz_s = None
+        # output layer: with both of its consumers on the split path dz goes straight out as an sx8 operand
+        # and its column sum (the bias gradient) follows from the [B, C] cotangents
+        W_out = params[4 * nh]
+        out_split = (nh > 0 and _split_ok(M, W_out.shape[0], split) and C % 8 == 0 and hs[nh - 1] is not None
+                     and ops.gemm_split_tn_shape_ok(M, C, hs[nh - 1].shape[1], C, hs[nh - 1].stride(0)))
+        if out_split:
+            dz, dz_s = None, ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C, sx8=True).view(M, C)
+            grads[4 * nh + 1] = ops.pool4_bwd_colsum(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C)
+        else:
+            dz = ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C).view(M, C)
+            dz_s = None
         # per-point MLP backward, output layer first.  Entering iteration i: dz = grad wrt the
         # pre-LN output of Linear i (fp32) and, in split mode, dz_s = the same in sx8.
         for i in range(nh, -1, -1):
@@ -125,7 +136,7 @@ class EncoderFn(torch.autograd.Function):
                 all_split = want_s and (tn_ok or (_split_ok(M, W.shape[1], split) and M % 8 == 0))
                 dz, grads[4 * i + 2], grads[4 * i + 3], grads[4 * i + 1] = ops.ln_act_bwd(
                     dh, zs[i], mu, rs, g, be, ACT_RELU, inplace=True, dz_split=dz_s, want_dz=not all_split)
-            else:
+            elif dz is not None:
                 grads[4 * i + 1] = ops.colsum(dz)
                 if nh and _split_ok(M, W.shape[0], split):
                     dz_s = ops.split_rows(dz)

@@ -215,15 +215,36 @@ def pool4_fwd(pf, valid):
     return mmax, mavg, umean, umax, arg_m, arg_u, cnt
 
 
-def pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C):
+def pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C, sx8=False):
+    """sx8=True: the result is written as an sx8 split operand (C % 8 == 0) instead of fp32."""
     _need_cuda(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct)
     for t in (dmmax, dmavg, dumean, dumax, dpf_direct):
         if t is not None and not t.is_contiguous():
             raise RuntimeError("wf3d.pool4_bwd: contiguous cotangents required")
     dpf = torch.empty(B, N, C, dtype=torch.float32, device=valid.device)
-    check(_lib.load().wf3d_pool4_bwd(_p(valid), _p(cnt), _p(arg_m), _p(arg_u), _p(dmmax), _p(dmavg), _p(dumean),
-                                     _p(dumax), _p(dpf_direct), B, N, C, _p(dpf), _stream()), "pool4_bwd")
+    fn = _lib.load().wf3d_pool4_bwd_sx8 if sx8 else _lib.load().wf3d_pool4_bwd
+    check(fn(_p(valid), _p(cnt), _p(arg_m), _p(arg_u), _p(dmmax), _p(dmavg), _p(dumean), _p(dumax), _p(dpf_direct),
+             B, N, C, _p(dpf), _stream()), "pool4_bwd")
     return dpf
+
+
+def pool4_bwd_colsum(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C):
+    """Column sums over all B*N rows of what pool4_bwd writes, from the [B, C] cotangents alone:
+    sum_n of  valid*dmavg/cnt + dumean/N + [n==arg_m]*dmmax + [n==arg_u]*dumax  (+ dpf_direct)."""
+    dev = valid.device
+    acc = torch.zeros(B, C, dtype=torch.float32, device=dev)
+    if dmavg is not None:
+        acc += dmavg * (valid.view(B, N).sum(1) / cnt.view(B)).unsqueeze(1)
+    if dumean is not None:
+        acc += dumean
+    if dmmax is not None:
+        acc += torch.where(arg_m >= 0, dmmax, torch.zeros_like(dmmax))
+    if dumax is not None:
+        acc += torch.where(arg_u >= 0, dumax, torch.zeros_like(dumax))
+    out = acc.sum(0)
+    if dpf_direct is not None:
+        out = out + colsum(dpf_direct.view(B * N, C))
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -443,6 +464,11 @@ def split_transpose(t, pro=None, in_sx8=False):
 
 def gemm_split_tn_ok(a_s, b_s):
     return bool(_lib.load().wf3d_gemm_split_tn_ok(a_s.shape[1], b_s.shape[1], a_s.shape[0], a_s.stride(0), b_s.stride(0)))
+
+
+def gemm_split_tn_shape_ok(K, Mo, No, lda, ldb):
+    """Same test from shapes alone (before the operand exists)."""
+    return bool(_lib.load().wf3d_gemm_split_tn_ok(Mo, No, K, lda, ldb))
 
 
 def gemm_split_tn(a_s, b_s, out=None, accumulate=False):
