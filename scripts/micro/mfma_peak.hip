@@ -114,6 +114,64 @@ static void run_rand(int iters, float* out) {
     printf("%-28s threads=512 blocks=256 iters=%d  %8.3f ms  %7.1f TFLOP/s\n", "random operands, 2 waves/SIMD", iters, ms, flop / ms / 1e9);
 }
 
+// LDS-fed 16x16x32 loops on random data: per k32 slice a wave re-reads its fragments from LDS like the split GEMM does.
+//   TILE 0: 128x64 per wave (8 x 4 accumulators): 16 A + 8 B ds_read_b128 per 96 MFMAs, 8 waves per CU (2 per SIMD)
+//   TILE 1: 128x128 per wave (8 x 8 accumulators): 16 A + 16 B reads per 192 MFMAs, 4 waves per CU (1 per SIMD)
+template <int TILE>
+__global__ __launch_bounds__(TILE ? 256 : 512) void mfma_lds_loop(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[32768];             // 128 KB
+    constexpr int NJ = TILE ? 8 : 4;
+    for (int i = threadIdx.x; i < 32768; i += blockDim.x) {
+        unsigned r = mix(i * 2654435761u + blockIdx.x), q = mix(r);
+        unsigned w = ((r & 0x807f807fu) | 0x3f003f00u);
+        lds[i] = __builtin_bit_cast(float, w ^ (q & 0x00010001u));
+    }
+    __syncthreads();
+    f32x4 acc[8][NJ];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = lds + wave * 2048 + lane * 4;                      // conflict-free: 16 B per lane, contiguous
+    for (int it = 0; it < iters; ++it) {
+        const float* p = base + (it & 3) * 256;
+        f32x4 bh[NJ], bl[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { bh[j] = *(const f32x4*)(p + j * 512); bl[j] = *(const f32x4*)(p + j * 512 + 4096); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 ah = *(const f32x4*)(p + 8192 + i * 512), al = *(const f32x4*)(p + 12288 + i * 512);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), __builtin_bit_cast(bf16x8, al), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), __builtin_bit_cast(bf16x8, ah), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), __builtin_bit_cast(bf16x8, ah), acc[i][j], 0, 0, 0);
+        }
+    }
+    float sacc = 0.f;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < NJ; ++j)
+            for (int e = 0; e < 4; ++e) sacc += acc[i][j][e];
+    if (sacc == 123.456f) out[threadIdx.x] = sacc;
+}
+
+template <int TILE>
+static void run_lds(int iters, float* out) {
+    const int threads = TILE ? 256 : 512;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_lds_loop<TILE>, dim3(256), dim3(threads), 0, 0, out, 16);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(mfma_lds_loop<TILE>, dim3(256), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 256.0 * (threads / 64) * iters * (TILE ? 192.0 : 96.0) * 16384.0;
+    printf("%-28s threads=%d blocks=256 iters=%d  %8.3f ms  %7.1f TFLOP/s\n",
+           TILE ? "LDS-fed 128x128/wave, 1/SIMD" : "LDS-fed 128x64/wave, 2/SIMD", threads, iters, ms, flop / ms / 1e9);
+}
+
 template <int NACC>
 static void run(const char* name, int threads, int blocks, int iters, float* out) {
     hipEvent_t e0, e1;
@@ -143,6 +201,8 @@ int main() {
         run_rand(40000, out);
         run_rand16(2000, out);
         run_rand16(40000, out);
+        run_lds<0>(4000, out);
+        run_lds<1>(4000, out);
     }
     return 0;
 }

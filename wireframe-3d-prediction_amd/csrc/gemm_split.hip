@@ -943,12 +943,18 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             return *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + (lo ? c_lo : c_hi));
         };
         f32x4 bh[4], bl[4], ah, al, ahn, aln;
+        // Reads in the order the MFMAs consume them, pinned: after the barrier both waves of a SIMD are in the
+        // same phase, so whatever the first MFMA waits for is exposed; it needs only the first two reads.
         al = rdA(0, true);
+        bh[0] = rdB(0, false);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bh[j] = rdB(j, false);
+        for (int j = 1; j < 4; ++j) bh[j] = rdB(j, false);
+        __builtin_amdgcn_sched_barrier(0);
         ah = rdA(0, false);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bl[j] = rdB(j, true);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (i < 7) {
@@ -976,6 +982,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
         asm volatile("" ::: "memory");
         stage ^= 1;
     }
+
 
     const bool split = p.ksplit > 1;
     const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
