@@ -26,6 +26,18 @@
 #define WF3D_DMA_SCHED 0   // 256x256 kernel: 0 = DMA pieces spread over the slice, 1 = over its first half, 2 = bunched at the top
 #endif
 
+#ifndef WF3D_STAMP
+#define WF3D_STAMP 0       // diagnostic build: per-slice s_memtime stamps around the DMA wait and the barrier (x16 kernel)
+#endif
+#if WF3D_STAMP
+__device__ unsigned long long wf3d_stamp_acc[8];
+extern "C" int wf3d_debug_stamps(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(wf3d_stamp_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(wf3d_stamp_acc), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -857,7 +869,12 @@ __device__ __forceinline__ f32x4 tr_frag16(const char* base, int off) {
 //              (then 8g+4..8g+7) and each receives its column's 4 k-values — exactly the 16x16x32 operand.
 template <bool TN>
 __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * T4_STAGE];      // 131,072 B
+    // All 160 KB of LDS: THREE stages for A (the operand streamed from HBM: its slice t+2 is in flight while t
+    // is multiplied) and two for B (weights / the other streamed operand: slice t+1).  Measured with in-kernel
+    // stamps (-DWF3D_STAMP) on the two-stage forward/dgrad kernel: 9-35 % of every slice was spent waiting for
+    // the A pieces issued one slice earlier — HBM read latency under the kernel's own C-store traffic is more
+    // than one slice (wgrad, which stores almost nothing: 2 %).
+    __shared__ __attribute__((aligned(16))) float smem[5 * T4_A];          // 163,840 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows wm*128, cols wn*64
@@ -911,27 +928,35 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 #pragma unroll
     for (int j = 0; j < 4; ++j) b_tn[j] = (8 * g + tq) * 1024 + ((2 * (wn * 8 + 2 * j + (tp >> 1))) ^ ftn) * 16 + (tp & 1) * 8;
 
-    {
+    float* const smemB = smem + 3 * T4_A;
+    {   // prologue: A(kt0), B(kt0), then A(kt0+1) — the wait below leaves exactly the last four in flight
         float* dA = smem + wave * 4 * 8 * SBK;
+        const size_t k1 = (size_t)min(kt0 + 1, kt1 - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dma16_asm(asrc[q] + kt0 * astep, dA + q * 8 * SBK);
-            dma16_asm(bsrc[q] + kt0 * bstep, dA + T4_A + q * 8 * SBK);
-        }
+        for (int q = 0; q < 4; ++q) dma16_asm(asrc[q] + kt0 * astep, dA + q * 8 * SBK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_asm(bsrc[q] + kt0 * bstep, smemB + wave * 4 * 8 * SBK + q * 8 * SBK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_asm(asrc[q] + k1 * astep, dA + T4_A + q * 8 * SBK);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    int stage = 0;
+    int stage = 0, astage = 0;                              // B ring of 2, A ring of 3
+#if WF3D_STAMP
+    unsigned long long st_compute = 0, st_dma = 0, st_bar = 0, st_n = 0, st_dma4 = 0;
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_loop_begin = st_prev;
+#endif
     for (int kt = kt0; kt < kt1; ++kt) {
-        float* dA = smem + (stage ^ 1) * T4_STAGE + wave * 4 * 8 * SBK;
-        float* dB = dA + T4_A;
-        // branch-free: the last iteration re-fetches its own slice into the idle stage
-        const size_t kn = (size_t)min(kt + 1, kt1 - 1);
-        const size_t ka = kn * astep, kb = kn * bstep;
-        const float* As = smem + stage * T4_STAGE;
-        const float* Bs = As + T4_A;
+        const int astage2 = astage == 0 ? 2 : astage - 1;                  // (astage + 2) % 3
+        float* dA = smem + astage2 * T4_A + wave * 4 * 8 * SBK;            // A(kt+2)
+        float* dB = smemB + (stage ^ 1) * T4_A + wave * 4 * 8 * SBK;       // B(kt+1)
+        // branch-free: past the end the DMA re-fetches the last slice into stages nobody reads again
+        const size_t ka = (size_t)min(kt + 2, kt1 - 1) * astep, kb = (size_t)min(kt + 1, kt1 - 1) * bstep;
+        const float* As = smem + astage * T4_A;
+        const float* Bs = smemB + stage * T4_A;
         const char* Ac = reinterpret_cast<const char*>(As);
         const char* Bc = reinterpret_cast<const char*>(Bs);
         auto rdA = [&](int i, bool lo) -> f32x4 {
@@ -962,9 +987,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
                 aln = rdA(i + 1, true);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (i < 4) {          // all 8 DMA pieces of the next slice within the first half of this one
-                if (i < 2) { dma16_asm(asrc[2 * i] + ka, dA + (2 * i) * 8 * SBK);         dma16_asm(asrc[2 * i + 1] + ka, dA + (2 * i + 1) * 8 * SBK); }
-                else       { dma16_asm(bsrc[2 * i - 4] + kb, dB + (2 * i - 4) * 8 * SBK); dma16_asm(bsrc[2 * i - 3] + kb, dB + (2 * i - 3) * 8 * SBK); }
+            if (i < 4) {          // B(kt+1) first, A(kt+2) last: the slice-end wait skips exactly the 4 youngest
+                if (i < 2) { dma16_asm(bsrc[2 * i] + kb, dB + (2 * i) * 8 * SBK);         dma16_asm(bsrc[2 * i + 1] + kb, dB + (2 * i + 1) * 8 * SBK); }
+                else       { dma16_asm(asrc[2 * i - 4] + ka, dA + (2 * i - 4) * 8 * SBK); dma16_asm(asrc[2 * i - 3] + ka, dA + (2 * i - 3) * 8 * SBK); }
             }
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
@@ -977,12 +1002,31 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             __builtin_amdgcn_sched_barrier(0);
             ah = ahn; al = aln;
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if WF3D_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st_compute += t1 - st_prev; st_dma += t2 - t1; st_bar += t3 - t2; st_prev = t3; ++st_n;
+        if (kt - kt0 < 4) st_dma4 += t2 - t1;
+#else
+        // B(kt+1) and A(kt+1) landed (all but the 4 youngest pieces = A(kt+2)); this wave's reads of the stages done
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
         stage ^= 1;
+        astage = astage == 2 ? 0 : astage + 1;
     }
-
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
+#if WF3D_STAMP
+    const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
     const bool split = p.ksplit > 1;
     const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
@@ -1024,6 +1068,18 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             }
         }
     }
+#if WF3D_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        atomicAdd(&wf3d_stamp_acc[0], st_compute); atomicAdd(&wf3d_stamp_acc[1], st_dma);
+        atomicAdd(&wf3d_stamp_acc[2], st_bar);     atomicAdd(&wf3d_stamp_acc[3], st_n);
+        atomicAdd(&wf3d_stamp_acc[4], t_end - t_loop_end);      // epilogue incl. store drain
+        atomicAdd(&wf3d_stamp_acc[5], t_loop_end - t_loop_begin);
+        atomicAdd(&wf3d_stamp_acc[6], 1ull);
+        atomicAdd(&wf3d_stamp_acc[7], st_dma4);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
