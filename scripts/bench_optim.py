@@ -1,0 +1,38 @@
+"""Row f-2 baseline: GPU time of train.py's step tail (clip_grad_norm_ + Adam.step + zero_grad) for this model."""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wireframe-3d-prediction_amd"))
+import torch
+from models.PointCloudToWireframe import PointCloudToWireframe
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = PointCloudToWireframe(input_dim=8, max_vertices=64).to(dev)
+model.vertex_predictor.ensure_point_pool_proj(1024, dev)
+params = [p for p in model.parameters()]
+for p in params:
+    p.grad = torch.randn_like(p) * 1e-3
+print("tensors", len(params), "elements", sum(p.numel() for p in params))
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return statistics.median(ts)
+
+
+for foreach in (None, False):
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-6, foreach=foreach)
+    t_clip = timeit(lambda: torch.nn.utils.clip_grad_norm_(params, max_norm=1.0, foreach=foreach))
+    t_step = timeit(lambda: opt.step())
+    print(f"foreach={foreach}: clip_grad_norm_ {t_clip:.3f} ms, Adam.step {t_step:.3f} ms")
+try:
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-6, fused=True)
+    print(f"fused=True: Adam.step {timeit(lambda: opt.step()):.3f} ms")
+except Exception as e:
+    print("fused Adam unavailable:", repr(e)[:120])

@@ -188,6 +188,72 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost,
     for (int p = lane; p < V; p += 64) col4row_out[(size_t)b * V + p] = col4row[p];
 }
 
+// V <= 64: the whole solver state lives in registers — lane j owns column j (v_j, shortest-path cost, predecessor,
+// row4col_j, visited flag) and row j (u_j, col4row_j); a uniform row/column index is read with v_readlane, the
+// arg-min is one fp64 wave minimum plus two ballots, and the cost matrix sits in LDS (<= 16 KB) instead of being
+// re-read from L2 once per path step.  Same algorithm, same tie rule as lsa_kernel.
+__device__ __forceinline__ double lane_read_f64(double x, int lane_uniform) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane_uniform);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), lane_uniform);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(64) void lsa64_kernel(const float* __restrict__ cost, int V, int32_t* __restrict__ col4row_out) {
+    __shared__ float Cs[64 * 64];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const float* C = cost + (size_t)b * V * V;
+    for (int idx = lane; idx < V * V; idx += 64) Cs[idx] = C[idx];
+    __syncthreads();
+    const bool col_ok = lane < V;
+    double u = 0.0, v = 0.0;
+    int row4col = -1, col4row = -1;
+    for (int cur = 0; cur < V; ++cur) {
+        double spc = INFINITY;
+        bool in_sc = !col_ok;
+        int path = -1;
+        int i = cur, sink = -1;
+        double min_val = 0.0;
+        unsigned long long sr_mask = 0ull;
+        while (sink < 0) {
+            sr_mask |= 1ull << i;
+            const double ui = lane_read_f64(u, i);
+            if (!in_sc) {
+                const double r = min_val + (double)Cs[i * V + lane] - ui - v;
+                if (r < spc) { spc = r; path = i; }
+            }
+            double m = in_sc ? INFINITY : spc;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+            const unsigned long long cand = __ballot(!in_sc && spc == m);
+            const unsigned long long fr = cand & __ballot(row4col < 0);
+            const int pick = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(fr ? fr : cand));
+            min_val = m;
+            if (lane == pick) in_sc = true;
+            const int r4c = __builtin_amdgcn_readlane(row4col, pick);
+            if (r4c < 0) sink = pick; else i = __builtin_amdgcn_readfirstlane(r4c);
+        }
+        // dual update: rows in SR (lane = row), columns in SC (lane = column)
+        {
+            const int c = col4row < 0 ? 0 : col4row;
+            const double spc_c = __shfl(spc, c, 64);
+            if ((sr_mask >> lane) & 1ull) u += (lane == cur) ? min_val : min_val - spc_c;
+            if (in_sc && col_ok) v -= min_val - spc;
+        }
+        // augment along the path (wave-uniform walk)
+        int j = sink;
+        while (true) {
+            const int r = __builtin_amdgcn_readlane(path, j);
+            if (lane == j) row4col = r;
+            const int prev = __builtin_amdgcn_readlane(col4row, r);
+            if (lane == r) col4row = j;
+            if (r == cur) break;
+            j = __builtin_amdgcn_readfirstlane(prev);
+        }
+    }
+    if (col_ok) col4row_out[(size_t)b * V + lane] = col4row;
+}
+
 // loss terms from the device assignment: prediction p of sample b is matched iff col4row[b,p] < count[b]
 __global__ __launch_bounds__(256) void loss_terms_dev_kernel(const float* __restrict__ verts, long vs_b, long vs_v,
                                                               const float* __restrict__ exist,
@@ -292,8 +358,12 @@ extern "C" int wf3d_loss_assign(const float* cost, int B, int V, int32_t* col4ro
     WF3D_CHECK(V <= 1024, WF3D_ERR_UNSUPPORTED, "wf3d_loss_assign: V > 1024");
     if (B == 0) return WF3D_OK;
     WF3D_CHECK(cost && col4row, WF3D_ERR_ARG, "wf3d_loss_assign: null pointer");
-    const size_t lds = (size_t)V * (3 * sizeof(double) + 4 * sizeof(int) + 1) + 16;
-    hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cost, V, col4row);
+    if (V <= 64) {
+        hipLaunchKernelGGL(lsa64_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cost, V, col4row);
+    } else {
+        const size_t lds = (size_t)V * (3 * sizeof(double) + 4 * sizeof(int) + 1) + 16;
+        hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cost, V, col4row);
+    }
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
