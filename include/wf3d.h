@@ -122,6 +122,20 @@ int wf3d_split_transpose(const float* in, int R, int C, int ld, const float* mu,
  * relu_ of PointNetEncoder.py:36-38 in the split path). */
 int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, const float* beta, int act, float eps,
                  float drop_p, uint32_t drop_seed, float* mu, float* rs, void* h_sx8, void* stream);
+/* First Linear of the per-point MLP (in_features K <= 8) fused with its LayerNorm / activation / split
+ * (models/PointNetEncoder.py:35-45, layer 0): writes z = x·W^T + b [R, D] (kept for backward), (mu, rstd) and
+ * h = act(LN(z)) in sx8 — one pass instead of a GEMM that writes z plus a normalisation pass that reads it back. */
+int wf3d_first_layer_fwd(const float* x, int R, int K, int ldx, const float* W, int ldw, const float* bias, int D,
+                         const float* gamma, const float* beta, int act, float eps, float* z, float* mu, float* rs,
+                         void* h_sx8, void* stream);
+/* ... and its backward: LayerNorm/activation backward of layer 0 that also accumulates that layer's weight
+ * gradient dW[D, K] = dz^T·x (K more weighted column sums) and never writes dz (the input takes no gradient).
+ * dgamma, dbeta, dbias must be one contiguous [3][D] buffer. */
+size_t wf3d_ln_act_bwd_first_ws_bytes(int R, int D);
+int wf3d_ln_act_bwd_first(const float* dh, const float* z, const float* x, int R, int D, int K, int ldx,
+                          const float* mu, const float* rs, const float* gamma, const float* beta, int act,
+                          float* dgamma, float* dbeta, float* dbias, float* dW, void* ws, size_t ws_bytes, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * LayerNorm pieces (nn.LayerNorm, eps 1e-5, biased variance — SURVEY App. A)

@@ -407,3 +407,26 @@ def test_gemm_split_tn_matches_transposed_nt_path(ops, K, Mo, No):
         gi = ops.gemm_split_tn(ops.split_rows(Ai), ops.split_rows(Bi))
         assert torch.equal(gi.cpu().double(), Ai.double().cpu().T @ Bi.double().cpu())
     assert not ops.gemm_split_tn_ok(ops.split_rows(rnd(64, 136, seed=3)), Bs[:64])
+
+
+@pytest.mark.parametrize("R,K,D", [(1000, 8, 512), (37, 3, 64), (4096, 8, 1024), (5, 8, 8)])
+def test_first_layer_fused_forward_and_backward(ops, R, K, D):
+    """Layer 0 of the per-point MLP: fused Linear+LN+ReLU+split forward == GEMM then ln_prep; fused backward
+    (LN/ReLU backward + bias + weight gradient, no dz) == ln_act_bwd + TN GEMM."""
+    x = rnd(R, K, seed=1)
+    x[::7] = 0.0
+    W, b = rnd(D, K, seed=2, scale=0.3), rnd(D, seed=3, scale=0.1)
+    gamma, beta = 1.0 + 0.1 * rnd(D, seed=4), 0.1 * rnd(D, seed=5)
+    assert ops.first_layer_ok(x, W)
+    z, mu, rs, hs = ops.first_layer_fwd(x, W, b, gamma, beta, ops.ACT_RELU)
+    z_ref = x.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    assert rel(z, z_ref) < TOL_ELT
+    mu2, rs2, hs2 = ops.ln_prep(z, gamma, beta, ops.ACT_RELU)
+    assert rel(mu, mu2) < 1e-5 and rel(rs, rs2) < 1e-6                    # same z, row sums in a different order
+    (h1, l1), (h2, l2) = unpack_sx8(hs), unpack_sx8(hs2)
+    assert rel(h1 + l1, h2 + l2) < 2e-5
+    dh = rnd(R, D, seed=6)
+    dg, db, dbias, dW = ops.ln_act_bwd_first(dh, z, x, mu, rs, gamma, beta, ops.ACT_RELU)
+    dz, dg2, db2, dbias2 = ops.ln_act_bwd(dh.clone(), z, mu, rs, gamma, beta, ops.ACT_RELU)
+    assert rel(dg, dg2) < 1e-5 and rel(db, db2) < 1e-5 and rel(dbias, dbias2) < 2e-5
+    assert rel(dW, dz.double().cpu().T @ x.double().cpu()) < 2e-5

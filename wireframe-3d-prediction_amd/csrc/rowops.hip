@@ -79,13 +79,18 @@ __global__ __launch_bounds__(256) void ln_act_apply_kernel(const float* __restri
 // so that the per-lane state stays small (<= ~100 VGPRs -> >= 4 waves per SIMD): with one wave
 // per 2048-wide row the kernel sat at 256 VGPRs / 1 wave per SIMD and 2.3 TB/s.  Row sums cross
 // the waves through a double-buffered LDS slot and one barrier per row group.
-template <int NS, int WPR>
+// KX > 0 (first Linear of the per-point MLP, in_features K <= KX): its weight gradient
+// dW[c, k] = sum_r dz[r, c] * x[r, k] is K more weighted column sums of the dz this kernel already holds in
+// registers, so they are accumulated here ([3 + KX][D] partials) and dz itself — which nothing else needs, the
+// input cloud takes no gradient — is never written.
+template <int NS, int WPR, int KX = 0>
 __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z,
                                                           int R, int D, const float* __restrict__ mu,
                                                           const float* __restrict__ rs, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, uint32_t seed,
                                                           uint32_t thresh, float scale, float* __restrict__ dz,
-                                                          float* __restrict__ dz_sx8, float* __restrict__ part) {
+                                                          float* __restrict__ dz_sx8, float* __restrict__ part,
+                                                          const float* __restrict__ x0 = nullptr, int ldx = 0, int kx = 0) {
     constexpr int RPI = 4 / WPR;                       // rows per workgroup iteration
     __shared__ float xsum[2][4][2];                    // [parity][wave][s1, s2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,12 +111,22 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
         }
         a_dg[i] = a_db[i] = a_dbias[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    f32x4 a_dw[KX > 0 ? KX : 1][NS];
+#pragma unroll
+    for (int k = 0; k < (KX > 0 ? KX : 1); ++k)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) a_dw[k][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float invD = 1.0f / (float)D;
     const int iters = (R + gridDim.x * RPI - 1) / (gridDim.x * RPI);
     for (int it = 0; it < iters; ++it) {
         const int row = (it * gridDim.x + blockIdx.x) * RPI + wrow;
         const bool live = row < R;
         const float m = (has_ln && live) ? mu[row] : 0.f, r = (has_ln && live) ? rs[row] : 1.f;
+        float xk[KX > 0 ? KX : 1];
+        if (KX > 0) {
+#pragma unroll
+            for (int k = 0; k < KX; ++k) xk[k] = (live && k < kx) ? x0[(size_t)row * ldx + k] : 0.f;
+        }
         f32x4 xh[NS], gg[NS];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -158,6 +173,10 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
                     o[j] = has_ln ? r * (g * gam[i][j] - c1 - x * c2) : g;
                     a_dg[i][j] += g * x; a_db[i][j] += g; a_dbias[i][j] += o[j];
                 }
+                if (KX > 0) {
+#pragma unroll
+                    for (int k = 0; k < KX; ++k) a_dw[k][i] += o * xk[k];
+                }
                 if (dz) *reinterpret_cast<f32x4*>(dz + (size_t)row * D + c) = o;
                 if (dz_sx8) {
                     // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts,
@@ -181,15 +200,16 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     }
     // column partials: waves of the same slice (different rows) combine through LDS, then one
     // partial row [3][D] per workgroup
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [3][D]
-    for (int k = 0; k < 3; ++k) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [3 + KX][D]
+#pragma unroll
+    for (int k = 0; k < 3 + KX; ++k) {
         for (int w = 0; w < RPI; ++w) {
             if (wrow == w) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const int c = cbeg + lane * 4 + 256 * i;
                     if (c < cend) {
-                        f32x4 v = k == 0 ? a_dg[i] : (k == 1 ? a_db[i] : a_dbias[i]);
+                        f32x4 v = k == 0 ? a_dg[i] : (k == 1 ? a_db[i] : (k == 2 ? a_dbias[i] : a_dw[k >= 3 ? k - 3 : 0][i]));
                         f32x4* dst = reinterpret_cast<f32x4*>(red + k * D + c);
                         if (w) v += *dst;
                         *dst = v;
@@ -199,7 +219,20 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
             __syncthreads();
         }
     }
-    for (int idx = threadIdx.x; idx < 3 * D; idx += 256) part[(size_t)blockIdx.x * 3 * D + idx] = red[idx];
+    for (int idx = threadIdx.x; idx < (3 + KX) * D; idx += 256) part[(size_t)blockIdx.x * (3 + KX) * D + idx] = red[idx];
+}
+
+// out[c * K + k] = sum_b part[b * stride + k * D + c]: the dW partials ([K][D] per block) folded and stored as
+// the weight's own [D][K] layout.
+__global__ __launch_bounds__(256) void colsum_finalize_t_kernel(const float* __restrict__ part, int nblk, size_t stride,
+                                                                 int D, int K, float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= D * K) return;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) { s0 += part[(size_t)b * stride + idx]; s1 += part[(size_t)(b + 1) * stride + idx]; }
+    if (b < nblk) s0 += part[(size_t)b * stride + idx];
+    out[(size_t)(idx % D) * K + idx / D] = s0 + s1;
 }
 
 // out[c] = sum_b part[b*stride + c].  32 columns per workgroup, the partial rows split 8 ways
@@ -340,6 +373,42 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
                            (size_t)3 * D, D, outs[k]);
         WF3D_LAUNCH_CHECK();
     }
+    return WF3D_OK;
+}
+
+extern "C" size_t wf3d_ln_act_bwd_first_ws_bytes(int R, int D) {
+    if (R <= 0 || D <= 0) return 0;
+    return (size_t)bwd_nblk(R) * (3 + 8) * D * sizeof(float);
+}
+
+extern "C" int wf3d_ln_act_bwd_first(const float* dh, const float* z, const float* x, int R, int D, int K, int ldx,
+                                     const float* mu, const float* rs, const float* gamma, const float* beta, int act,
+                                     float* dgamma, float* dbeta, float* dbias, float* dW, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    WF3D_CHECK(R > 0 && D > 0 && K > 0 && K <= 8 && ldx >= K, WF3D_ERR_UNSUPPORTED, "wf3d_ln_act_bwd_first: needs R > 0, 1 <= K <= 8");
+    WF3D_CHECK(D % 4 == 0 && D <= 1024, WF3D_ERR_UNSUPPORTED, "wf3d_ln_act_bwd_first: D=%d must be a multiple of 4, <= 1024", D);
+    WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_ln_act_bwd_first: bad act");
+    WF3D_CHECK(dh && z && x && mu && rs && gamma && beta && dgamma && dbeta && dbias && dW, WF3D_ERR_ARG,
+               "wf3d_ln_act_bwd_first: null pointer");
+    WF3D_CHECK(dbeta == dgamma + D && dbias == dbeta + D, WF3D_ERR_ARG, "wf3d_ln_act_bwd_first: dgamma/dbeta/dbias must be one [3][D] buffer");
+    WF3D_CHECK(((uintptr_t)dh % 16 == 0) && ((uintptr_t)z % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0),
+               WF3D_ERR_ARG, "wf3d_ln_act_bwd_first: pointers must be 16-byte aligned");
+    const int nblk = bwd_nblk(R);
+    WF3D_CHECK(ws && ws_bytes >= (size_t)nblk * 11 * D * sizeof(float), WF3D_ERR_WS, "wf3d_ln_act_bwd_first: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const size_t lds = (size_t)11 * D * sizeof(float);
+    const int wpr = D > 512 ? 4 : (D > 256 ? 2 : 1);
+#define WF3D_BWD1(WPR_)                                                                                                  \
+    hipLaunchKernelGGL((ln_act_bwd_kernel<1, WPR_, 8>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
+                       act, 0u, 0u, 1.0f, (float*)nullptr, (float*)nullptr, part, x, ldx, K)
+    if (wpr == 4) WF3D_BWD1(4); else if (wpr == 2) WF3D_BWD1(2); else WF3D_BWD1(1);
+#undef WF3D_BWD1
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)11 * D, 3 * D, dgamma);
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_t_kernel, dim3(wf3d_cdiv(D * K, 256)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)11 * D, D, K, dW);
+    WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
 

@@ -102,6 +102,84 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 }
 
 
+// First Linear of the per-point MLP fused with its LayerNorm / activation / split
+// (PointNetEncoder.py:35-45 with in_features = input_dim = 8): z = x·W^T + b is a pure
+// 2 KB-per-row WRITE (K <= 8: 8 FMAs per output), so instead of a GEMM that writes z and an
+// ln_prep pass that reads it back, one wave per row computes the row in registers from its
+// slice of W (kept in registers across rows), and writes z (kept for backward), (mu, rstd)
+// and h = act(LN(z)) in sx8.  Column layout per lane as in ln_prep_kernel.
+template <int NS>
+__global__ __launch_bounds__(256) void first_layer_kernel(const float* __restrict__ x, int ldx, int K,
+                                                           const float* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, int R, int D,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int act, float eps, float* __restrict__ z,
+                                                           float* __restrict__ mu, float* __restrict__ rs,
+                                                           float* __restrict__ h_sx8) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w[NS][8][8], b[NS][8];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = lane * 8 + 512 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            b[i][j] = (c < D && bias) ? bias[c + j] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[i][j][k] = (c < D && k < K) ? W[(size_t)(c + j) * ldw + k] : 0.f;
+        }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        float xr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xr[k] = k < K ? x[(size_t)row * ldx + k] : 0.f;
+        float v[NS][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 8 + 512 * i;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a = fmaf(xr[k], w[i][j][k], a);
+                v[i][j] = c < D ? a + b[i][j] : 0.f;
+                s += v[i][j];
+            }
+            if (c < D) {
+                float* zp = z + (size_t)row * D + c;
+                *reinterpret_cast<f32x4*>(zp) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+                *reinterpret_cast<f32x4*>(zp + 4) = f32x4{v[i][4], v[i][5], v[i][6], v[i][7]};
+            }
+        }
+        const float mean = wf3d_wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < D)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+        const float rstd = 1.0f / sqrtf(wf3d_wave_sum(q) / (float)D + eps);
+        if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < D) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * g0[j] + b0[j]);
+                    o[4 + j] = wf3d_act_rt(act, (v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+                }
+                store_sx8(h_sx8 + (size_t)row * D + c, o);
+            }
+        }
+    }
+}
+
 // out_sx8[c, r] = split( pro(in[r, c]) ): tiled transpose through LDS so that both the
 // fp32 reads (256 B per 16 lanes) and the sx8 writes (128 B per 4 lanes) are coalesced.
 // pro = optional act(LN-affine(.)) with per-row (mu, rs) and per-column (gamma, beta):
@@ -211,6 +289,28 @@ extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, co
                        drop_seed, thresh, dscale, mu, rs, (float*)h_sx8)
     if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
 #undef WF3D_LP
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_first_layer_fwd(const float* x, int R, int K, int ldx, const float* W, int ldw, const float* bias,
+                                    int D, const float* gamma, const float* beta, int act, float eps, float* z,
+                                    float* mu, float* rs, void* h_sx8, void* stream) {
+    WF3D_CHECK(R >= 0 && K > 0 && K <= 8 && ldx >= K && ldw >= K, WF3D_ERR_UNSUPPORTED,
+               "wf3d_first_layer_fwd: needs 1 <= K <= 8 (K=%d)", K);
+    WF3D_CHECK(D > 0 && D % 8 == 0 && D <= 1024, WF3D_ERR_UNSUPPORTED, "wf3d_first_layer_fwd: D=%d must be a multiple of 8, <= 1024", D);
+    WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_first_layer_fwd: bad act");
+    if (R == 0) return WF3D_OK;
+    WF3D_CHECK(x && W && gamma && beta && z && mu && rs && h_sx8, WF3D_ERR_ARG, "wf3d_first_layer_fwd: null pointer");
+    WF3D_CHECK(((uintptr_t)z % 16 == 0) && ((uintptr_t)h_sx8 % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+               ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_first_layer_fwd: pointers must be 16-byte aligned");
+    int blocks = wf3d_cdiv(R, 4 * 8);                    // ~8 rows per wave: the W slice is loaded once per wave
+    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 512) hipLaunchKernelGGL((first_layer_kernel<1>), dim3(blocks), dim3(256), 0, st, x, ldx, K, W, ldw, bias, R, D,
+                                     gamma, beta, act, eps, z, mu, rs, (float*)h_sx8);
+    else          hipLaunchKernelGGL((first_layer_kernel<2>), dim3(blocks), dim3(256), 0, st, x, ldx, K, W, ldw, bias, R, D,
+                                     gamma, beta, act, eps, z, mu, rs, (float*)h_sx8);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

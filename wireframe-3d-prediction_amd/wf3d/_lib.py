@@ -65,6 +65,12 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_pool4_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_first_layer_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf3d_ln_act_bwd_first_ws_bytes": (c_size_t, [c_int, c_int]),
+    "wf3d_ln_act_bwd_first": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
     "wf3d_pool4_bwd_sx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -66,16 +66,23 @@ class EncoderFn(torch.autograd.Function):
         for i in range(n_hidden + 1):
             last = i == n_hidden
             W, b = params[4 * i], params[4 * i + 1]
-            if a_s is not None:
+            fused0 = (i == 0 and not last and _split_ok(M, W.shape[0], split) and ops.first_layer_ok(x2, W))
+            if fused0:
+                # first Linear + LayerNorm + ReLU + split in one pass (K = input_dim <= 8: a pure write of z and h)
+                z, mu, rs, a_s = ops.first_layer_fwd(x2, W, b, params[2], params[3], ACT_RELU)
+            elif a_s is not None:
                 z = ops.gemm_split(a_s, ops.split_rows(W), bias=b)
+                a_s = None
             else:
                 z = ops.gemm(a, W, NT, bias=b, pro=pro)
-            a_s = None
+                a_s = None
             if last:
                 pf = z
                 break
             g, be = params[4 * i + 2], params[4 * i + 3]
-            if _split_ok(M, z.shape[1], split):
+            if fused0:
+                pass
+            elif _split_ok(M, z.shape[1], split):
                 mu, rs, a_s = ops.ln_prep(z, g, be, ACT_RELU)
             else:
                 mu, rs = ops.row_stats(z)
@@ -126,6 +133,11 @@ class EncoderFn(torch.autograd.Function):
         # pre-LN output of Linear i (fp32) and, in split mode, dz_s = the same in sx8.
         for i in range(nh, -1, -1):
             W = params[4 * i]
+            if i == 0 and nh > 0 and _split_ok(M, W.shape[0], split) and ops.first_layer_ok(x2, W):
+                # layer 0: LN/ReLU backward, bias and WEIGHT gradient in one pass over (dh, z); dz is never written
+                g, be = params[2], params[3]
+                grads[2], grads[3], grads[1], grads[0] = ops.ln_act_bwd_first(dh, zs[0], x2, stats[0][0], stats[0][1], g, be, ACT_RELU)
+                break
             if i < nh:
                 g, be = params[4 * i + 2], params[4 * i + 3]
                 mu, rs = stats[i]

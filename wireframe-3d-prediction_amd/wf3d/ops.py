@@ -425,6 +425,42 @@ def ln_prep(z, gamma, beta, act, eps=LN_EPS, drop_p=0.0, seed=0):
     return mu, rs, h
 
 
+def first_layer_ok(x, W):
+    """Shapes the fused first-layer kernels take: in_features <= 8, out_features a multiple of 8 up to 1024."""
+    return x.dim() == 2 and x.shape[1] <= 8 and W.shape[0] % 8 == 0 and W.shape[0] <= 1024 and x.stride(1) == 1 and W.stride(1) == 1
+
+
+def first_layer_fwd(x, W, bias, gamma, beta, act, eps=LN_EPS):
+    """x [R, K<=8] -> (z = x·W^T + b, mu, rs, h_sx8 = act(LayerNorm(z))) in one pass."""
+    _need_cuda(x, W, bias, gamma, beta)
+    R, K = x.shape
+    D = W.shape[0]
+    z = torch.empty(R, D, dtype=torch.float32, device=x.device)
+    h = torch.empty_like(z)
+    mu = torch.empty(R, dtype=torch.float32, device=x.device)
+    rs = torch.empty(R, dtype=torch.float32, device=x.device)
+    check(_lib.load().wf3d_first_layer_fwd(_p(x), R, K, x.stride(0), _p(W), W.stride(0), _p(bias), D, _p(gamma), _p(beta),
+                                           act, eps, _p(z), _p(mu), _p(rs), _p(h), _stream()), "first_layer_fwd")
+    return z, mu, rs, h
+
+
+def ln_act_bwd_first(dh, z, x, mu, rs, gamma, beta, act):
+    """Backward of act(LayerNorm(z)) for the first layer: (dgamma, dbeta, dbias, dW[D, K]); dz is not materialised."""
+    _need_cuda(dh, z, x, mu, rs, gamma, beta)
+    if not (dh.is_contiguous() and z.is_contiguous()):
+        raise RuntimeError("wf3d.ln_act_bwd_first: contiguous tensors required")
+    R, D = z.shape
+    K = x.shape[1]
+    trio = torch.empty(3, D, dtype=torch.float32, device=z.device)
+    dW = torch.empty(D, K, dtype=torch.float32, device=z.device)
+    lib = _lib.load()
+    ws = scratch(lib.wf3d_ln_act_bwd_first_ws_bytes(R, D), z.device)
+    check(lib.wf3d_ln_act_bwd_first(_p(dh), _p(z), _p(x), R, D, K, x.stride(0), _p(mu), _p(rs), _p(gamma), _p(beta), act,
+                                    _p(trio[0]), _p(trio[1]), _p(trio[2]), _p(dW), _p(ws), ws.numel(), _stream()),
+          "ln_act_bwd_first")
+    return trio[0], trio[1], trio[2], dW
+
+
 def gemm_split(a_s, b_s, bias=None, out=None, accumulate=False):
     """C[M,N] = A·B^T (+bias) with A = sx8[M,K], B = sx8[N,K] (bf16x3: hi*hi + hi*lo + lo*hi, fp32 accumulate)."""
     _need_cuda(a_s, b_s, bias, out)
