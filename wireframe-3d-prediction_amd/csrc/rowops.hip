@@ -222,23 +222,12 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     for (int idx = threadIdx.x; idx < (3 + KX) * D; idx += 256) part[(size_t)blockIdx.x * (3 + KX) * D + idx] = red[idx];
 }
 
-// out[c * K + k] = sum_b part[b * stride + k * D + c]: the dW partials ([K][D] per block) folded and stored as
-// the weight's own [D][K] layout.
-__global__ __launch_bounds__(256) void colsum_finalize_t_kernel(const float* __restrict__ part, int nblk, size_t stride,
-                                                                 int D, int K, float* __restrict__ out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= D * K) return;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 1 < nblk; b += 2) { s0 += part[(size_t)b * stride + idx]; s1 += part[(size_t)(b + 1) * stride + idx]; }
-    if (b < nblk) s0 += part[(size_t)b * stride + idx];
-    out[(size_t)(idx % D) * K + idx / D] = s0 + s1;
-}
-
 // out[c] = sum_b part[b*stride + c].  32 columns per workgroup, the partial rows split 8 ways
 // over the thread groups (coalesced 128-B reads, 4 loads in flight per thread), combined through LDS.
+// tK > 0: column c = k * tD + d is stored at out[d * tK + k] (the [K][D] weight-gradient partials of the first
+// layer land in the weight's own [D][K] layout).
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, size_t stride,
-                                                               int D, float* __restrict__ out) {
+                                                               int D, float* __restrict__ out, int tD = 0, int tK = 0) {
     __shared__ float red[8][32];
     const int col = threadIdx.x & 31, sub = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + col;
@@ -259,7 +248,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][col];
-        out[c] = t;
+        out[tK > 0 ? (size_t)(c % tD) * tK + c / tD : (size_t)c] = t;
     }
 }
 
@@ -407,7 +396,7 @@ extern "C" int wf3d_ln_act_bwd_first(const float* dh, const float* z, const floa
     WF3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)11 * D, 3 * D, dgamma);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_t_kernel, dim3(wf3d_cdiv(D * K, 256)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)11 * D, D, K, dW);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D * K, 32)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)11 * D, D * K, dW, D, K);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

@@ -6,6 +6,8 @@
 // hi = bf16_rne(v), lo = bf16_rne(v - hi)  (|v - hi - lo| <= 2^-17 |v|).  A staged
 // row slice then delivers each lane's v_mfma_f32_32x32x16_bf16 fragment (8
 // consecutive k) as one 16-byte chunk, with no conversion inside the GEMM.
+#include <stdlib.h>
+
 #include "wf3d_common.h"
 
 namespace {
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 // ln_prep pass that reads it back, one wave per row computes the row in registers from its
 // slice of W (kept in registers across rows), and writes z (kept for backward), (mu, rstd)
 // and h = act(LN(z)) in sx8.  Column layout per lane as in ln_prep_kernel.
-template <int NS>
+// FAST: K == 8, 16-byte aligned x rows and ReLU — two float4 loads per row, no per-element branches.
+template <int NS, bool FAST>
 __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restrict__ x, int ldx, int K,
                                                            const float* __restrict__ W, int ldw,
                                                            const float* __restrict__ bias, int R, int D,
@@ -128,10 +131,25 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
             for (int k = 0; k < 8; ++k) w[i][j][k] = (c < D && k < K) ? W[(size_t)(c + j) * ldw + k] : 0.f;
         }
     }
+    // the next row's x is requested before this row is computed and stored (one row ~ a memory round trip otherwise)
+    auto load_x = [&](int row, float (&xr)[8]) {
+        if (FAST) {
+            const float* px = x + (size_t)min(row, R - 1) * ldx;           // clamped: the value of a row >= R is never used
+            const f32x4 a = *reinterpret_cast<const f32x4*>(px), c4 = *reinterpret_cast<const f32x4*>(px + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xr[k] = a[k]; xr[4 + k] = c4[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xr[k] = (row < R && k < K) ? x[(size_t)row * ldx + k] : 0.f;
+        }
+    };
+    float xn[8];
+    load_x(blockIdx.x * 4 + wave, xn);
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         float xr[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xr[k] = k < K ? x[(size_t)row * ldx + k] : 0.f;
+        for (int k = 0; k < 8; ++k) xr[k] = xn[k];
+        load_x(row + gridDim.x * 4, xn);
         float v[NS][8];
         float s = 0.f;
 #pragma unroll
@@ -171,8 +189,9 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * g0[j] + b0[j]);
-                    o[4 + j] = wf3d_act_rt(act, (v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+                    const float y0 = (v[i][j] - mean) * rstd * g0[j] + b0[j], y1 = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+                    o[j] = FAST ? fmaxf(y0, 0.f) : wf3d_act_rt(act, y0);
+                    o[4 + j] = FAST ? fmaxf(y1, 0.f) : wf3d_act_rt(act, y1);
                 }
                 store_sx8(h_sx8 + (size_t)row * D + c, o);
             }
@@ -304,13 +323,18 @@ extern "C" int wf3d_first_layer_fwd(const float* x, int R, int K, int ldx, const
     WF3D_CHECK(x && W && gamma && beta && z && mu && rs && h_sx8, WF3D_ERR_ARG, "wf3d_first_layer_fwd: null pointer");
     WF3D_CHECK(((uintptr_t)z % 16 == 0) && ((uintptr_t)h_sx8 % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
                ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_first_layer_fwd: pointers must be 16-byte aligned");
-    int blocks = wf3d_cdiv(R, 4 * 8);                    // ~8 rows per wave: the W slice is loaded once per wave
-    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+    // persistent: two workgroups per CU (512 measured best of 512..8192), each wave keeps its slice of W in registers for all its rows
+    static const int fl_blocks = [] { const char* e = getenv("WF3D_FL_BLOCKS"); return e ? atoi(e) : 512; }();
+    int blocks = wf3d_cdiv(R, 4);
+    blocks = blocks > fl_blocks ? fl_blocks : (blocks < 1 ? 1 : blocks);
     hipStream_t st = (hipStream_t)stream;
-    if (D <= 512) hipLaunchKernelGGL((first_layer_kernel<1>), dim3(blocks), dim3(256), 0, st, x, ldx, K, W, ldw, bias, R, D,
-                                     gamma, beta, act, eps, z, mu, rs, (float*)h_sx8);
-    else          hipLaunchKernelGGL((first_layer_kernel<2>), dim3(blocks), dim3(256), 0, st, x, ldx, K, W, ldw, bias, R, D,
-                                     gamma, beta, act, eps, z, mu, rs, (float*)h_sx8);
+    const bool fast = K == 8 && ldx % 4 == 0 && ((uintptr_t)x % 16 == 0) && act == WF3D_ACT_RELU;
+#define WF3D_FL(NS_, F_)                                                                                               \
+    hipLaunchKernelGGL((first_layer_kernel<NS_, F_>), dim3(blocks), dim3(256), 0, st, x, ldx, K, W, ldw, bias, R, D, gamma, \
+                       beta, act, eps, z, mu, rs, (float*)h_sx8)
+    if (D <= 512) { if (fast) WF3D_FL(1, true); else WF3D_FL(1, false); }
+    else          { if (fast) WF3D_FL(2, true); else WF3D_FL(2, false); }
+#undef WF3D_FL
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
