@@ -430,3 +430,16 @@ def test_first_layer_fused_forward_and_backward(ops, R, K, D):
     dz, dg2, db2, dbias2 = ops.ln_act_bwd(dh.clone(), z, mu, rs, gamma, beta, ops.ACT_RELU)
     assert rel(dg, dg2) < 1e-5 and rel(db, db2) < 1e-5 and rel(dbias, dbias2) < 2e-5
     assert rel(dW, dz.double().cpu().T @ x.double().cpu()) < 2e-5
+
+
+def test_wgrad_through_the_transposed_problem(ops):
+    """dW[128, 256] = dz^T·h does not tile (Mo % 256 != 0) but its transpose does: functional._wgrad_tn computes
+    h^T·dz and transposes the small result (third edge-MLP layer, EdgePredictor.py:64)."""
+    from wf3d import functional as F
+    K, Mo, No = 4096, 128, 256
+    dz, h = rnd(K, Mo, seed=1), rnd(K, No, seed=2)
+    dz_s, h_s = ops.split_rows(dz), ops.split_rows(h)
+    assert not ops.gemm_split_tn_ok(dz_s, h_s) and ops.gemm_split_tn_ok(h_s, dz_s) and F._tn_either(dz_s, h_s)
+    got = F._wgrad_tn(dz_s, h_s)
+    assert got.shape == (Mo, No) and got.is_contiguous()
+    assert rel(got, dz.double().cpu().T @ h.double().cpu()) < TOL_SPLIT

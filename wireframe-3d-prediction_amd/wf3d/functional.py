@@ -36,6 +36,18 @@ def _split_ok(rows, k, split):
     return split and rows >= config.SPLIT_MIN_ROWS and k % 8 == 0 and k >= 32
 
 
+def _tn_either(a_s, b_s):
+    """The wgrad kernel tiles dW[Mo, No] with Mo % 256 == 0; when only the transposed problem fits
+    (e.g. dW[128, 256]) it computes dW^T = h^T·dz and the small result is transposed."""
+    return ops.gemm_split_tn_ok(a_s, b_s) or ops.gemm_split_tn_ok(b_s, a_s)
+
+
+def _wgrad_tn(dz_s, h_s):
+    if ops.gemm_split_tn_ok(dz_s, h_s):
+        return ops.gemm_split_tn(dz_s, h_s)
+    return ops.gemm_split_tn(h_s, dz_s).t().contiguous()
+
+
 class EncoderFn(torch.autograd.Function):
     """x[B,N,Din], params -> (pooled[B,2C] = [masked max | masked mean], point_features[B,N,C],
     umean[B,C], umax[B,C]).
@@ -363,22 +375,22 @@ class EdgeFn(torch.autograd.Function):
         tsplit = ctx.split and meta.Re % 8 == 0              # (transposed) wgrad operands need whole 8-row groups
         if ctx.split:
             dz3_s = torch.empty_like(dh3)
-            tn3 = ops.gemm_split_tn_ok(dh3, h2)             # dz3_s has dh3's shape
+            tn3 = _tn_either(dh3, h2)                       # dz3_s has dh3's shape
             dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True,
                                               dz_split=dz3_s, want_dz=not (tsplit or tn3))
-            if ops.gemm_split_tn_ok(dz3_s, h2):
-                G[20] = ops.gemm_split_tn(dz3_s, h2)
+            if tn3:
+                G[20] = _wgrad_tn(dz3_s, h2)
             else:
                 G[20] = (ops.gemm_split(ops.split_transpose(dz3_s, in_sx8=True), ops.split_transpose(z2, p2)) if tsplit
                          else ops.gemm(dz3, z2, TN, pro=p2))
             dh2 = ops.gemm_split(dz3_s, ops.split_rows(M8w, transpose=True))
             del dz3, dz3_s
             dz2_s = torch.empty_like(dh2)
-            tn2 = ops.gemm_split_tn_ok(dh2, h1)
+            tn2 = _tn_either(dh2, h1)
             dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3],
                                                       inplace=True, dz_split=dz2_s, want_dz=not (tsplit or tn2))
-            if ops.gemm_split_tn_ok(dz2_s, h1):
-                G[16] = ops.gemm_split_tn(dz2_s, h1)
+            if tn2:
+                G[16] = _wgrad_tn(dz2_s, h1)
             else:
                 G[16] = (ops.gemm_split(ops.split_transpose(dz2_s, in_sx8=True), ops.split_transpose(pre, p1)) if tsplit
                          else ops.gemm(dz2, pre, TN, pro=p1))
