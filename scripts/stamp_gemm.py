@@ -13,7 +13,7 @@ lib.wf3d_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = torch.device("cuda:0")
 M = 131072
 buf = (ctypes.c_ulonglong * 8)()
-for K, N, tn in [(512, 1024, False), (1024, 2048, False), (2048, 1024, False), (1024, 512, False), (2048, 1024, True)]:
+for K, N, tn in [(1024, 256, False), (512, 1024, False), (1024, 2048, False), (2048, 1024, False), (1024, 512, False), (2048, 1024, True)]:
     if tn:
         A, B = ops.split_rows(torch.randn(M, K, device=dev)), ops.split_rows(torch.randn(M, N, device=dev))
         fn = lambda: ops.gemm_split_tn(A, B)
@@ -31,5 +31,5 @@ for K, N, tn in [(512, 1024, False), (1024, 2048, False), (2048, 1024, False), (
     per = (comp + dma + bar) / n
     print(f"{'TN' if tn else 'NT'} K={K} N={N}: per slice {per:7.0f} ticks = compute {comp / n:7.0f} ({100 * comp / (comp + dma + bar):4.1f}%) "
           f"+ dma-wait {dma / n:6.0f} ({100 * dma / (comp + dma + bar):4.1f}%) + barrier {bar / n:6.0f} ({100 * bar / (comp + dma + bar):4.1f}%); "
-          f"dma-wait first 4 slices of a tile {dma4 / (4 * waves):6.0f}/slice, later slices {(dma - dma4) / max(n - 4 * waves, 1):6.0f}/slice; "
+          f"of which waiting for A(kt+1) after the first 4 slices of a tile {dma4 / max(n - 4 * waves, 1):6.0f}/slice; "
           f"per wave: loop {loop / waves:9.0f}  epilogue {epi / waves:8.0f} ticks ({100 * epi / (epi + loop):4.1f}% of loop+epilogue)")

@@ -1005,15 +1005,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 #if WF3D_STAMP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");          // A(kt+1), issued a slice ago
+        const unsigned long long t1b = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");          // + B(kt+1), issued at the top of this slice
         const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        if (kt - kt0 >= 4) st_dma4 += t1b - t1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const unsigned long long t3 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         st_compute += t1 - st_prev; st_dma += t2 - t1; st_bar += t3 - t2; st_prev = t3; ++st_n;
-        if (kt - kt0 < 4) st_dma4 += t2 - t1;
 #else
         // B(kt+1) and A(kt+1) landed (all but the 4 youngest pieces = A(kt+2)); this wave's reads of the stages done
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
