@@ -235,6 +235,12 @@ int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* ctx, const f
 int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
                        const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
                        float* pre, float* mu, float* rs, float* delta, void* stream);
+/* Same, and also h = drop(act(LayerNorm(pre))) as the sx8 operand of the next Linear (edge_mlp[1..4] of
+ * EdgePredictor.py:57-60) from the row the wave still holds: saves wf3d_ln_prep's second read of pre. */
+int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
+                          const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
+                          float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
+                          float drop_p, uint32_t drop_seed, void* h_sx8, void* stream);
 /* dPa[v] / dPb[v] = segmented sums of dpre over the edges where v is i / j, and
  * dcv[v] = sum over incident edges of (dpre[e]·wdelta)(c_v - c_other)/delta[e]. */
 int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,

@@ -443,3 +443,21 @@ def test_wgrad_through_the_transposed_problem(ops):
     got = F._wgrad_tn(dz_s, h_s)
     assert got.shape == (Mo, No) and got.is_contiguous()
     assert rel(got, dz.double().cpu().T @ h.double().cpu()) < TOL_SPLIT
+
+
+@pytest.mark.parametrize("H,counts,drop", [(512, [9, 2, 5], 0.0), (64, [4, 7], 0.0), (512, [6, 6], 0.1), (1024, [3, 8], 0.0)])
+def test_pair_forward_also_emits_the_next_operand(ops, H, counts, drop):
+    """edge_pair_fwd(ln=...) == edge_pair_fwd followed by ln_prep on the row it wrote (incl. the dropout mask)."""
+    meta = ops.EdgeMeta(counts, dev())
+    Pa, Pb = rnd(meta.Rv, H, seed=1), rnd(meta.Rv, H, seed=2)
+    cv = rnd(meta.Rv, 3, seed=3)
+    W0 = rnd(H, 2 * H + 7, seed=4, scale=0.2)
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=5), 0.1 * rnd(H, seed=6)
+    pre, mu, rs, delta = ops.edge_pair_fwd(Pa, Pb, cv, W0, meta)
+    pre2, mu2, rs2, delta2, h = ops.edge_pair_fwd(Pa, Pb, cv, W0, meta, ln=(gamma, beta, ops.ACT_GELU, drop, 1234))
+    assert torch.equal(pre, pre2) and torch.equal(mu, mu2) and torch.equal(rs, rs2) and torch.equal(delta, delta2)
+    mu3, rs3, h3 = ops.ln_prep(pre, gamma, beta, ops.ACT_GELU, drop_p=drop, seed=1234)
+    (a, b), (c, d) = unpack_sx8(h), unpack_sx8(h3)
+    assert rel(a + b, c + d) < 2e-5
+    if drop:
+        assert torch.equal((a + b) == 0, (c + d) == 0)          # identical dropout mask

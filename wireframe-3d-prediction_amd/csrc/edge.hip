@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
                                                         const int32_t* __restrict__ eoff,
                                                         const int32_t* __restrict__ esample, int Re, int H, float eps,
                                                         float* __restrict__ pre, float* __restrict__ mu,
-                                                        float* __restrict__ rs, float* __restrict__ delta) {
+                                                        float* __restrict__ rs, float* __restrict__ delta,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int act, uint32_t seed, uint32_t thresh, float dscale,
+                                                        float* __restrict__ h_sx8) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= Re) return;
@@ -98,10 +101,40 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
         }
     }
     const float var = wf3d_wave_sum(q) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
     if (lane == 0) {
         mu[e] = mean;
-        rs[e] = 1.0f / sqrtf(var + eps);
+        rs[e] = rstd;
         delta[e] = dl;
+    }
+    // h = drop(act(LN(pre))) as the sx8 operand of the next Linear, from the row the wave still holds
+    // (what wf3d_ln_prep would produce from a second read of pre; same dropout counter: row e, column c).
+    if (h_sx8) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int c = lane * 4 + 256 * t;
+            if (c < H) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c), b4 = *reinterpret_cast<const f32x4*>(beta + c);
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = wf3d_act_rt(act, (val[t][k] - mean) * rstd * g4[k] + b4[k]);
+                    if (thresh) o[k] = wf3d_keep(seed, (uint32_t)e, (uint32_t)(c + k), thresh) ? o[k] * dscale : 0.f;
+                }
+                // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts, odd lane the 8 low parts
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { hi[k] = (__bf16)o[k]; lo[k] = (__bf16)(o[k] - (float)hi[k]); }
+                const uint2 mine_hi = __builtin_bit_cast(uint2, hi), mine_lo = __builtin_bit_cast(uint2, lo);
+                const bool odd = lane & 1;
+                uint2 send = odd ? mine_hi : mine_lo, got;
+                got.x = __shfl_xor((int)send.x, 1, 64);
+                got.y = __shfl_xor((int)send.y, 1, 64);
+                const uint4 w = odd ? make_uint4(got.x, got.y, mine_lo.x, mine_lo.y) : make_uint4(mine_hi.x, mine_hi.y, got.x, got.y);
+                *reinterpret_cast<uint4*>(h_sx8 + (size_t)e * H + (c & ~7) + (odd ? 4 : 0)) = w;
+            }
+        }
     }
 }
 
@@ -254,10 +287,38 @@ extern "C" int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, i
     return WF3D_OK;
 }
 
+static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
+                         const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
+                         float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
+                         float drop_p, uint32_t drop_seed, void* h_sx8, void* stream);
+
 extern "C" int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const float* wdelta,
                                   int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample,
                                   int Re, int H, float eps, float* pre, float* mu, float* rs, float* delta,
                                   void* stream) {
+    return pair_fwd_impl(Pa, Pb, cv, wdelta, wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, nullptr,
+                         nullptr, 0, 0.f, 0u, nullptr, stream);
+}
+
+extern "C" int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const float* cv, const float* wdelta,
+                                     int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample,
+                                     int Re, int H, float eps, float* pre, float* mu, float* rs, float* delta,
+                                     const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
+                                     void* h_sx8, void* stream) {
+    WF3D_CHECK(gamma && beta && h_sx8, WF3D_ERR_ARG, "wf3d_edge_pair_fwd_ln: null pointer");
+    WF3D_CHECK(H % 8 == 0 && ((uintptr_t)h_sx8 % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0),
+               WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_fwd_ln: needs hidden %% 8 == 0 and 16-byte aligned pointers");
+    WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_edge_pair_fwd_ln: bad act/drop");
+    return pair_fwd_impl(Pa, Pb, cv, wdelta, wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, gamma, beta,
+                         act, drop_p, drop_seed, h_sx8, stream);
+}
+
+static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
+                         const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
+                         float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
+                         float drop_p, uint32_t drop_seed, void* h_sx8, void* stream) {
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float dscale = 1.0f / (1.0f - drop_p);
     WF3D_CHECK(Re >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_fwd: bad dims");
     WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_fwd: hidden %d must be a multiple of 4, <= 2048", H);
     if (Re == 0) return WF3D_OK;
@@ -267,7 +328,8 @@ extern "C" int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float*
     hipStream_t st = (hipStream_t)stream;
 #define WF3D_PF(NS_)                                                                                                 \
     hipLaunchKernelGGL((pair_fwd_kernel<NS_>), dim3(wf3d_cdiv(Re, 4)), dim3(256), 0, st, Pa, Pb, cv, wdelta,           \
-                       wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta)
+                       wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, gamma, beta, act, drop_seed,    \
+                       thresh, dscale, (float*)h_sx8)
     if (ns <= 1) WF3D_PF(1); else if (ns <= 2) WF3D_PF(2); else if (ns <= 4) WF3D_PF(4); else WF3D_PF(8);
 #undef WF3D_PF
     WF3D_LAUNCH_CHECK();

@@ -330,12 +330,15 @@ class EdgeFn(torch.autograd.Function):
         ops.gemm(cv, Wc, NT, out=Pa, accumulate=True)
         Pb = ops.gemm(Fm, Wb, NT)
         ops.gemm(cv, Wd, NT, out=Pb, accumulate=True)
-        pre, mu0, rs0, delta = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta)
-        del Pa, Pb
         # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
         split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
         if split:
-            mu0, rs0, h1 = ops.ln_prep(pre, M1g, M1b, ACT_GELU, drop_p=p1_, seed=sd[2])
+            # the pair kernel holds each edge row in registers: it also emits gelu(LN(pre)) as the next GEMM's operand
+            pre, mu0, rs0, delta, h1 = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta, ln=(M1g, M1b, ACT_GELU, p1_, sd[2]))
+        else:
+            pre, mu0, rs0, delta = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta)
+        del Pa, Pb
+        if split:
             z2 = ops.gemm_split(h1, ops.split_rows(M4w), bias=M4b)
             mu2, rs2, h2 = ops.ln_prep(z2, M5g, M5b, ACT_GELU, drop_p=p2_, seed=sd[3])
             s2 = (mu2, rs2)

@@ -348,7 +348,8 @@ def _wdelta(W0, H):
     return W0[:, 2 * H + 6].contiguous(), 1
 
 
-def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS):
+def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None):
+    """ln = (gamma, beta, act, drop_p, seed): also return h = drop(act(LayerNorm(pre))) as an sx8 operand."""
     _need_cuda(Pa, Pb, cv, W0)
     H = Pa.shape[1]
     wd, stride = _wdelta(W0, H)
@@ -357,10 +358,19 @@ def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS):
     mu = torch.empty(meta.Re, dtype=torch.float32, device=dev)
     rs = torch.empty(meta.Re, dtype=torch.float32, device=dev)
     delta = torch.empty(meta.Re, dtype=torch.float32, device=dev)
-    check(_lib.load().wf3d_edge_pair_fwd(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
-                                         _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
-                                         _stream()), "edge_pair_fwd")
-    return pre, mu, rs, delta
+    if ln is None:
+        check(_lib.load().wf3d_edge_pair_fwd(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
+                                             _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
+                                             _stream()), "edge_pair_fwd")
+        return pre, mu, rs, delta
+    gamma, beta, act, drop_p, seed = ln
+    _need_cuda(gamma, beta)
+    h = torch.empty_like(pre)
+    check(_lib.load().wf3d_edge_pair_fwd_ln(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
+                                            _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
+                                            _p(gamma), _p(beta), act, float(drop_p), int(seed) & 0xFFFFFFFF, _p(h),
+                                            _stream()), "edge_pair_fwd_ln")
+    return pre, mu, rs, delta, h
 
 
 def edge_pair_bwd(dpre, delta, cv, W0, meta):
