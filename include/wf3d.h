@@ -170,6 +170,16 @@ size_t wf3d_colsum_ws_bytes(int R, int D);
 int wf3d_colsum(const float* x, int R, int D, int ld, const float* w, int act, float* out, void* ws,
                 size_t ws_bytes, void* stream);
 
+/* One-output Linear on act(z) — the logits layer edge_mlp[9..10] (models/EdgePredictor.py:66-67) — as a row dot
+ * product, D = 8 * 2^k <= 512:  out[r] = bias[0] + sum_c act(z[r,c]) * w[c].
+ * Backward, fused with the activation backward below it: dz[r,c] = dlogit[r] * w[c] * act'(z[r,c]) (fp32 and / or
+ * sx8), dw[c] = sum_r dlogit[r] * act(z[r,c]), dbias_z[c] = sum_r dz[r,c]; dw and dbias_z are one [2][D] buffer. */
+int wf3d_rowdot_act_ok(int D);
+int wf3d_rowdot_act(const float* z, int R, int D, const float* w, const float* bias, int act, float* out, void* stream);
+size_t wf3d_rowdot_act_bwd_ws_bytes(int R, int D);
+int wf3d_rowdot_act_bwd(const float* z, const float* dlogit, int R, int D, const float* w, int act, float* dz,
+                        void* dz_sx8, float* dw, float* dbias_z, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Pools (PointNetEncoder.py:85-86,103-111 and VertexPredictor.py:86-88)
  * ------------------------------------------------------------------------ */

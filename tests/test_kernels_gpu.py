@@ -461,3 +461,25 @@ def test_pair_forward_also_emits_the_next_operand(ops, H, counts, drop):
     assert rel(a + b, c + d) < 2e-5
     if drop:
         assert torch.equal((a + b) == 0, (c + d) == 0)          # identical dropout mask
+
+
+@pytest.mark.parametrize("R,D", [(1000, 128), (37, 8), (4099, 512), (64, 64)])
+def test_rowdot_logits_layer_forward_and_fused_backward(ops, R, D):
+    """One-output Linear on gelu(z): row-dot forward == GEMM with GELU prologue; fused backward == the NN GEMM +
+    activation backward + weighted / plain column sums it replaces."""
+    z, W, b = rnd(R, D, seed=1), rnd(1, D, seed=2, scale=0.3), rnd(1, seed=3)
+    assert ops.rowdot_act_ok(z, W)
+    out = ops.rowdot_act(z, W, b, ops.ACT_GELU)
+    ref = torch.nn.functional.gelu(z.double().cpu()) @ W.double().cpu().T + b.double().cpu()
+    assert out.shape == (R, 1) and rel(out, ref) < 2e-5
+    t = rnd(R, 1, seed=4)
+    dzs = torch.empty_like(z)
+    dz, dW, dbz = ops.rowdot_act_bwd(z, t, W, ops.ACT_GELU, want_dz=True, dz_split=dzs)
+    zc = z.double().cpu().requires_grad_()
+    (torch.nn.functional.gelu(zc) @ W.double().cpu().T * t.double().cpu()).sum().backward()
+    assert rel(dz, zc.grad) < 2e-5
+    hi, lo = unpack_sx8(dzs)
+    assert rel(hi + lo, zc.grad) < 3e-5
+    assert rel(dW, (t.double().cpu().T @ torch.nn.functional.gelu(z.double().cpu()))) < 2e-5
+    assert rel(dbz, zc.grad.sum(0)) < 2e-5
+    assert not ops.rowdot_act_ok(rnd(8, 24, seed=5), rnd(1, 24, seed=6))       # 24/8 = 3 lanes per row: not a power of two

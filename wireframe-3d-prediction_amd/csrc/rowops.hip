@@ -264,6 +264,92 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[(size_t)blockIdx.y * D + c] = s;
 }
 
+// ---- one-output Linear on act(z): the logits layer edge_mlp[9..10] (EdgePredictor.py:66-67) -------------
+// A 1-wide GEMM wastes 127/128 of an MFMA tile; it is a row dot product.  Lanes: LPR = D/8 lanes per row
+// (8 consecutive columns each), 64/LPR rows per wave.
+template <int LPR>
+__global__ __launch_bounds__(256) void rowdot_act_kernel(const float* __restrict__ z, int R, int D,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          int act, float* __restrict__ out) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsub = lane / LPR;
+    const int row = (blockIdx.x * 4 + wave) * RPW + rsub;
+    const int c = sub * 8;
+    float s = 0.f;
+    if (row < R) {
+        const float* p = z + (size_t)row * D + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(w + c), wb = *reinterpret_cast<const f32x4*>(w + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += wf3d_act_rt(act, a[j]) * wa[j] + wf3d_act_rt(act, b[j]) * wb[j];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0 && row < R) out[row] = s + (bias ? bias[0] : 0.f);
+}
+
+// backward of the same layer fused with the activation backward of the layer below:
+//   dz[r,c] = t_r * w[c] * act'(z[r,c])   (t = d logit),   dW[c] = sum_r t_r * act(z[r,c]),   dbz[c] = sum_r dz[r,c]
+// dz goes out as the sx8 operand of the next dgrad / wgrad (and / or fp32); partial column sums per workgroup.
+template <int LPR>
+__global__ __launch_bounds__(256) void rowdot_act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                              int R, int D, const float* __restrict__ w, int act,
+                                                              float* __restrict__ dz, float* __restrict__ dz_sx8,
+                                                              float* __restrict__ part) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float red[4 * RPW][2][LPR * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsub = lane / LPR;
+    const int c = sub * 8;
+    float wv[8], adw[8], adb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wv[j] = w[c + j]; adw[j] = 0.f; adb[j] = 0.f; }
+    for (int row = (blockIdx.x * 4 + wave) * RPW + rsub; row < R; row += gridDim.x * 4 * RPW) {
+        const float tr = t[row];
+        const float* p = z + (size_t)row * D + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zv = j < 4 ? a[j] : b[j - 4];
+            o[j] = tr * wv[j] * wf3d_act_grad_rt(act, zv);
+            adw[j] += tr * wf3d_act_rt(act, zv);
+            adb[j] += o[j];
+        }
+        if (dz) {
+            float* q = dz + (size_t)row * D + c;
+            *reinterpret_cast<f32x4*>(q) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+        if (dz_sx8) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (__bf16)o[j]; lo[j] = (__bf16)(o[j] - (float)hi[j]); }
+            float* q = dz_sx8 + (size_t)row * D + c;
+            *reinterpret_cast<f32x4*>(q) = __builtin_bit_cast(f32x4, hi);
+            *reinterpret_cast<f32x4*>(q + 4) = __builtin_bit_cast(f32x4, lo);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[wave * RPW + rsub][0][c + j] = adw[j]; red[wave * RPW + rsub][1][c + j] = adb[j]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+        const int k = idx / D, col = idx % D;
+        float sacc = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4 * RPW; ++g) sacc += red[g][k][col];        // fixed order: deterministic
+        part[(size_t)blockIdx.x * 2 * D + idx] = sacc;
+    }
+}
+
+int rowdot_nblk(int R, int rpw) {
+    int n = wf3d_cdiv(R, 4 * rpw * 8);
+    return n > 1024 ? 1024 : (n < 1 ? 1 : n);
+}
+bool rowdot_ok(int D) { return D >= 8 && D <= 512 && D % 8 == 0 && ((D / 8) & (D / 8 - 1)) == 0; }
+
 int bwd_nblk(int R) {
     int n = wf3d_cdiv(R, 4);
     return n > 1024 ? 1024 : (n < 1 ? 1 : n);
@@ -397,6 +483,51 @@ extern "C" int wf3d_ln_act_bwd_first(const float* dh, const float* z, const floa
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)11 * D, 3 * D, dgamma);
     WF3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D * K, 32)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)11 * D, D * K, dW, D, K);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_rowdot_act_ok(int D) { return rowdot_ok(D) ? 1 : 0; }
+
+extern "C" int wf3d_rowdot_act(const float* z, int R, int D, const float* w, const float* bias, int act, float* out,
+                               void* stream) {
+    WF3D_CHECK(R >= 0 && rowdot_ok(D), WF3D_ERR_UNSUPPORTED, "wf3d_rowdot_act: D=%d must be 8 * 2^k, <= 512", D);
+    WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_rowdot_act: bad act");
+    if (R == 0) return WF3D_OK;
+    WF3D_CHECK(z && w && out && ((uintptr_t)z % 16 == 0) && ((uintptr_t)w % 16 == 0), WF3D_ERR_ARG, "wf3d_rowdot_act: null or misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int lpr = D / 8;
+#define WF3D_RD(L_) hipLaunchKernelGGL((rowdot_act_kernel<L_>), dim3(wf3d_cdiv(R, 4 * (64 / L_))), dim3(256), 0, st, z, R, D, w, bias, act, out)
+    switch (lpr) { case 1: WF3D_RD(1); break; case 2: WF3D_RD(2); break; case 4: WF3D_RD(4); break; case 8: WF3D_RD(8); break;
+                   case 16: WF3D_RD(16); break; case 32: WF3D_RD(32); break; default: WF3D_RD(64); break; }
+#undef WF3D_RD
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" size_t wf3d_rowdot_act_bwd_ws_bytes(int R, int D) {
+    if (R <= 0 || !rowdot_ok(D)) return 0;
+    return (size_t)rowdot_nblk(R, 64 / (D / 8)) * 2 * D * sizeof(float);
+}
+
+extern "C" int wf3d_rowdot_act_bwd(const float* z, const float* dlogit, int R, int D, const float* w, int act, float* dz,
+                                   void* dz_sx8, float* dw, float* dbias_z, void* ws, size_t ws_bytes, void* stream) {
+    WF3D_CHECK(R > 0 && rowdot_ok(D), WF3D_ERR_UNSUPPORTED, "wf3d_rowdot_act_bwd: D=%d must be 8 * 2^k, <= 512", D);
+    WF3D_CHECK(act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_rowdot_act_bwd: bad act");
+    WF3D_CHECK(z && dlogit && w && (dz || dz_sx8) && dw && dbias_z && dbias_z == dw + D, WF3D_ERR_ARG,
+               "wf3d_rowdot_act_bwd: null pointer, or dw / dbias_z not one [2][D] buffer");
+    WF3D_CHECK(((uintptr_t)z % 16 == 0) && ((uintptr_t)dz % 16 == 0) && ((uintptr_t)dz_sx8 % 16 == 0), WF3D_ERR_ARG,
+               "wf3d_rowdot_act_bwd: pointers must be 16-byte aligned");
+    const int lpr = D / 8, nblk = rowdot_nblk(R, 64 / lpr);
+    WF3D_CHECK(ws && ws_bytes >= (size_t)nblk * 2 * D * sizeof(float), WF3D_ERR_WS, "wf3d_rowdot_act_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+#define WF3D_RB(L_) hipLaunchKernelGGL((rowdot_act_bwd_kernel<L_>), dim3(nblk), dim3(256), 0, st, z, dlogit, R, D, w, act, dz, (float*)dz_sx8, part)
+    switch (lpr) { case 1: WF3D_RB(1); break; case 2: WF3D_RB(2); break; case 4: WF3D_RB(4); break; case 8: WF3D_RB(8); break;
+                   case 16: WF3D_RB(16); break; case 32: WF3D_RB(32); break; default: WF3D_RB(64); break; }
+#undef WF3D_RB
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(2 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)2 * D, 2 * D, dw);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

@@ -71,6 +71,11 @@ SIGNATURES = {
     "wf3d_ln_act_bwd_first": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "wf3d_rowdot_act_ok": (c_int, [c_int]),
+    "wf3d_rowdot_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "wf3d_rowdot_act_bwd_ws_bytes": (c_size_t, [c_int, c_int]),
+    "wf3d_rowdot_act_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_pool4_bwd_sx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -347,7 +347,10 @@ class EdgeFn(torch.autograd.Function):
             h1 = h2 = None
             z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])); s2 = ops.row_stats(z2)
             z3 = ops.gemm(z2, M8w, NT, bias=M8b, pro=Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3]))
-        logit = ops.gemm(z3, M10w, NT, bias=M10b, pro=Pro(ACT_GELU))
+        if ops.rowdot_act_ok(z3, M10w):
+            logit = ops.rowdot_act(z3, M10w, M10b, ACT_GELU)          # one-output Linear: a row dot product, not a GEMM
+        else:
+            logit = ops.gemm(z3, M10w, NT, bias=M10b, pro=Pro(ACT_GELU))
         probs = ops.edge_prob_fwd(logit, meta)
         ctx.params, ctx.cfg = params, (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
         ctx.split = split
@@ -366,7 +369,10 @@ class EdgeFn(torch.autograd.Function):
         G = [None] * len(params)
         dlogit = ops.edge_prob_bwd(probs, dprobs.contiguous(), meta)                      # [Re,1]
         G[23] = ops.colsum(dlogit)
-        if M10w.shape[0] == 1:
+        fused_tail = ops.rowdot_act_ok(z3, M10w)
+        if fused_tail:
+            dh3 = z3            # shape / dtype stand-in: the fused kernel below produces dz3 directly
+        elif M10w.shape[0] == 1:
             # one-output Linear: dW[c] = sum_r dlogit[r]*gelu(z3[r,c]) is a weighted column sum,
             # d gelu(z3) = dlogit (outer) W — no 128x128 MFMA tile wasted on a 1-wide problem
             G[22] = ops.colsum(z3, dlogit.view(-1), ACT_GELU).view(1, -1)
@@ -379,8 +385,12 @@ class EdgeFn(torch.autograd.Function):
         if ctx.split:
             dz3_s = torch.empty_like(dh3)
             tn3 = _tn_either(dh3, h2)                       # dz3_s has dh3's shape
-            dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True,
-                                              dz_split=dz3_s, want_dz=not (tsplit or tn3))
+            if fused_tail:
+                # logits-layer backward + GELU backward + both column sums in one pass over z3
+                dz3, G[22], G[21] = ops.rowdot_act_bwd(z3, dlogit, M10w, ACT_GELU, want_dz=not (tsplit or tn3), dz_split=dz3_s)
+            else:
+                dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True,
+                                                  dz_split=dz3_s, want_dz=not (tsplit or tn3))
             if tn3:
                 G[20] = _wgrad_tn(dz3_s, h2)
             else:
@@ -400,7 +410,10 @@ class EdgeFn(torch.autograd.Function):
             dh1 = ops.gemm_split(dz2_s, ops.split_rows(M4w, transpose=True))
             del dz2, dz2_s
         else:
-            dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True)
+            if fused_tail:
+                dz3, G[22], G[21] = ops.rowdot_act_bwd(z3, dlogit, M10w, ACT_GELU)
+            else:
+                dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True)
             G[20], dh2 = _lin_bwd(dz3, z2, M8w, p2)
             dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3], inplace=True)
             G[16], dh1 = _lin_bwd(dz2, pre, M4w, p1)

@@ -186,6 +186,37 @@ def colsum(x, w=None, act=ACT_NONE):
     return out
 
 
+def rowdot_act_ok(z, W):
+    """The row-dot kernels take a one-output Linear on a contiguous [R, D] with D = 8 * 2^k <= 512."""
+    return (W.shape[0] == 1 and z.dim() == 2 and z.is_contiguous() and W.is_contiguous()
+            and bool(_lib.load().wf3d_rowdot_act_ok(z.shape[1])))
+
+
+def rowdot_act(z, W, bias, act):
+    """[R, 1] = act(z) @ W^T + bias for a one-output Linear W [1, D]."""
+    _need_cuda(z, W, bias)
+    R, D = z.shape
+    out = torch.empty(R, 1, dtype=torch.float32, device=z.device)
+    check(_lib.load().wf3d_rowdot_act(_p(z), R, D, _p(W), _p(bias), act, _p(out), _stream()), "rowdot_act")
+    return out
+
+
+def rowdot_act_bwd(z, dlogit, W, act, want_dz=True, dz_split=None):
+    """Backward of rowdot_act fused with the activation backward: (dz | None, dW [1, D], dbias_z [D]);
+    `dz_split` (optional sx8 buffer) also receives dz."""
+    _need_cuda(z, dlogit, W, dz_split)
+    R, D = z.shape
+    if not want_dz and dz_split is None:
+        raise RuntimeError("wf3d.rowdot_act_bwd: want_dz=False needs dz_split")
+    dz = torch.empty_like(z) if want_dz else None
+    duo = torch.empty(2, D, dtype=torch.float32, device=z.device)
+    lib = _lib.load()
+    ws = scratch(lib.wf3d_rowdot_act_bwd_ws_bytes(R, D), z.device)
+    check(lib.wf3d_rowdot_act_bwd(_p(z), _p(dlogit), R, D, _p(W), act, _p(dz), _p(dz_split), _p(duo[0]), _p(duo[1]),
+                                  _p(ws), ws.numel(), _stream()), "rowdot_act_bwd")
+    return dz, duo[0].view(1, D), duo[1]
+
+
 def point_valid(x):
     _need_cuda(x)
     if not x.is_contiguous():
