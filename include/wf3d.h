@@ -135,6 +135,13 @@ size_t wf3d_ln_act_bwd_first_ws_bytes(int R, int D);
 int wf3d_ln_act_bwd_first(const float* dh, const float* z, const float* x, int R, int D, int K, int ldx,
                           const float* mu, const float* rs, const float* gamma, const float* beta, int act,
                           float* dgamma, float* dbeta, float* dbias, float* dW, void* ws, size_t ws_bytes, void* stream);
+/* LayerNorm / activation backward that also returns one weighted column sum of the dz it produces,
+ * wsum[c] = sum_r dz[r, c] * wrow[r] — for the first edge layer (models/EdgePredictor.py:130-137) the gradient of the
+ * weight column that multiplies the pair distance — instead of a second pass over dz.  dgamma, dbeta: one [2][D] buffer. */
+size_t wf3d_ln_act_bwd_wsum_ws_bytes(int R, int D);
+int wf3d_ln_act_bwd_wsum(const float* dh, const float* z, const float* wrow, int R, int D, const float* mu, const float* rs,
+                         const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed, float* dz,
+                         void* dz_sx8, float* dgamma, float* dbeta, float* wsum, void* ws, size_t ws_bytes, void* stream);
 
 
 /* ------------------------------------------------------------------------

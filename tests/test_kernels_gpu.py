@@ -483,3 +483,15 @@ def test_rowdot_logits_layer_forward_and_fused_backward(ops, R, D):
     assert rel(dW, (t.double().cpu().T @ torch.nn.functional.gelu(z.double().cpu()))) < 2e-5
     assert rel(dbz, zc.grad.sum(0)) < 2e-5
     assert not ops.rowdot_act_ok(rnd(8, 24, seed=5), rnd(1, 24, seed=6))       # 24/8 = 3 lanes per row: not a power of two
+
+
+@pytest.mark.parametrize("R,D,drop", [(777, 512, 0.0), (100, 64, 0.1), (300, 1024, 0.0), (64, 2048, 0.0)])
+def test_ln_act_bwd_with_weighted_column_sum(ops, R, D, drop):
+    """ln_act_bwd_wsum == ln_act_bwd, plus wsum == colsum(dz, wrow) without the second pass."""
+    z, dh, wrow = rnd(R, D, seed=1), rnd(R, D, seed=2), rnd(R, seed=3).abs()
+    gamma, beta = 1.0 + 0.1 * rnd(D, seed=4), 0.1 * rnd(D, seed=5)
+    mu, rs = ops.row_stats(z)
+    dz, dg, db, _ = ops.ln_act_bwd(dh.clone(), z, mu, rs, gamma, beta, ops.ACT_GELU, drop, 77, want_bias=False)
+    dz2, dg2, db2, wsum = ops.ln_act_bwd_wsum(dh.clone(), z, wrow, mu, rs, gamma, beta, ops.ACT_GELU, drop, 77)
+    assert torch.equal(dz, dz2) and rel(dg, dg2) < 1e-6 and rel(db, db2) < 1e-6
+    assert rel(wsum, (dz.double().cpu() * wrow.double().cpu()[:, None]).sum(0)) < 2e-5

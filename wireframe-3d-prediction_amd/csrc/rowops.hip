@@ -487,6 +487,49 @@ extern "C" int wf3d_ln_act_bwd_first(const float* dh, const float* z, const floa
     return WF3D_OK;
 }
 
+extern "C" size_t wf3d_ln_act_bwd_wsum_ws_bytes(int R, int D) {
+    if (R <= 0 || D <= 0) return 0;
+    return (size_t)bwd_nblk(R) * 4 * D * sizeof(float);
+}
+
+// LayerNorm / activation backward that also returns one weighted column sum of the dz it produces:
+// wsum[c] = sum_r dz[r, c] * wrow[r]   (first edge layer: the gradient of the distance column of its weight,
+// wrow = |c_i - c_j| per edge row — EdgePredictor.py:130-137 — without a second pass over dz).
+extern "C" int wf3d_ln_act_bwd_wsum(const float* dh, const float* z, const float* wrow, int R, int D, const float* mu,
+                                    const float* rs, const float* gamma, const float* beta, int act, float drop_p,
+                                    uint32_t drop_seed, float* dz, void* dz_sx8, float* dgamma, float* dbeta, float* wsum,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    WF3D_CHECK(R > 0 && D > 0 && D % 4 == 0 && D <= 4096, WF3D_ERR_UNSUPPORTED, "wf3d_ln_act_bwd_wsum: bad dims R=%d D=%d", R, D);
+    WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_ln_act_bwd_wsum: bad act/drop");
+    WF3D_CHECK(dh && z && wrow && mu && rs && gamma && beta && (dz || dz_sx8) && dgamma && dbeta && wsum && dbeta == dgamma + D,
+               WF3D_ERR_ARG, "wf3d_ln_act_bwd_wsum: null pointer, or dgamma / dbeta not one [2][D] buffer");
+    WF3D_CHECK(!dz_sx8 || (D % 8 == 0 && (uintptr_t)dz_sx8 % 16 == 0), WF3D_ERR_UNSUPPORTED, "wf3d_ln_act_bwd_wsum: sx8 output needs D %% 8 == 0");
+    WF3D_CHECK(((uintptr_t)dh % 16 == 0) && ((uintptr_t)z % 16 == 0) && ((uintptr_t)dz % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+               ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_ln_act_bwd_wsum: pointers must be 16-byte aligned");
+    const int nblk = bwd_nblk(R);
+    WF3D_CHECK(ws && ws_bytes >= (size_t)nblk * 4 * D * sizeof(float), WF3D_ERR_WS, "wf3d_ln_act_bwd_wsum: workspace too small");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float scale = 1.0f / (1.0f - drop_p);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const size_t lds = (size_t)4 * D * sizeof(float);
+    const int wpr = D > 512 ? 4 : (D > 256 ? 2 : 1);
+    const int ns = wf3d_cdiv(wf3d_cdiv(D / 4, wpr) * 4, 256);
+#define WF3D_BWDW(NS_, WPR_)                                                                                             \
+    hipLaunchKernelGGL((ln_act_bwd_kernel<NS_, WPR_, 1>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
+                       act, drop_seed, thresh, scale, dz, (float*)dz_sx8, part, wrow, 1, 1)
+    if (wpr == 4) { if (ns <= 1) WF3D_BWDW(1, 4); else if (ns <= 2) WF3D_BWDW(2, 4); else WF3D_BWDW(4, 4); }
+    else if (wpr == 2) WF3D_BWDW(1, 2);
+    else WF3D_BWDW(1, 1);
+#undef WF3D_BWDW
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(2 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)4 * D, 2 * D, dgamma);
+    WF3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)4 * D, D, wsum);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
 extern "C" int wf3d_rowdot_act_ok(int D) { return rowdot_ok(D) ? 1 : 0; }
 
 extern "C" int wf3d_rowdot_act(const float* z, int R, int D, const float* w, const float* bias, int act, float* out,

@@ -71,6 +71,10 @@ SIGNATURES = {
     "wf3d_ln_act_bwd_first": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "wf3d_ln_act_bwd_wsum_ws_bytes": (c_size_t, [c_int, c_int]),
+    "wf3d_ln_act_bwd_wsum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_float, ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     "wf3d_rowdot_act_ok": (c_int, [c_int]),
     "wf3d_rowdot_act": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "wf3d_rowdot_act_bwd_ws_bytes": (c_size_t, [c_int, c_int]),

@@ -417,10 +417,11 @@ class EdgeFn(torch.autograd.Function):
             G[20], dh2 = _lin_bwd(dz3, z2, M8w, p2)
             dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3], inplace=True)
             G[16], dh1 = _lin_bwd(dz2, pre, M4w, p1)
-        dpre, G[14], G[15], _ = ops.ln_act_bwd(dh1, pre, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], want_bias=False, inplace=True)
+        # LN/GELU backward of the first edge layer; the same pass yields the gradient of its distance-weight column
+        dpre, G[14], G[15], wsum = ops.ln_act_bwd_wsum(dh1, pre, delta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], inplace=True)
         # split first layer backward
         dW0 = torch.zeros_like(M0w)
-        dW0[:, 2 * H + 6].copy_(ops.colsum(dpre, delta))
+        dW0[:, 2 * H + 6].copy_(wsum)
         dPa, dPb, dcv = ops.edge_pair_bwd(dpre, delta, cv, M0w, meta)
         G[13] = ops.colsum(dPa)
         ops.gemm(dPa, Fm, TN, out=dW0[:, :H])

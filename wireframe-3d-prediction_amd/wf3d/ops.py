@@ -172,6 +172,23 @@ def ln_act_bwd(dh, z, mu, rs, gamma, beta, act, drop_p=0.0, seed=0, want_affine=
     return dz, dgamma, dbeta, dbias
 
 
+def ln_act_bwd_wsum(dh, z, wrow, mu, rs, gamma, beta, act, drop_p=0.0, seed=0, inplace=False):
+    """(dz, dgamma, dbeta, wsum) with wsum[c] = sum_r dz[r, c] * wrow[r] from the same pass."""
+    _need_cuda(dh, z, wrow, mu, rs, gamma, beta)
+    if not (dh.is_contiguous() and z.is_contiguous() and wrow.is_contiguous()):
+        raise RuntimeError("wf3d.ln_act_bwd_wsum: contiguous tensors required")
+    R, D = z.shape
+    dz = dh if inplace else torch.empty_like(z)
+    duo = torch.empty(2, D, dtype=torch.float32, device=z.device)
+    wsum = torch.empty(D, dtype=torch.float32, device=z.device)
+    lib = _lib.load()
+    ws = scratch(lib.wf3d_ln_act_bwd_wsum_ws_bytes(R, D), z.device)
+    check(lib.wf3d_ln_act_bwd_wsum(_p(dh), _p(z), _p(wrow), R, D, _p(mu), _p(rs), _p(gamma), _p(beta), act, float(drop_p),
+                                   int(seed) & 0xFFFFFFFF, _p(dz), None, _p(duo[0]), _p(duo[1]), _p(wsum), _p(ws),
+                                   ws.numel(), _stream()), "ln_act_bwd_wsum")
+    return dz, duo[0], duo[1], wsum
+
+
 def colsum(x, w=None, act=ACT_NONE):
     """out[c] = sum_r act(x[r, c]) * w[r]"""
     _need_cuda(x, w)
