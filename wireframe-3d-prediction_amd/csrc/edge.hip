@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void scatter_dverts_kernel(const float* __rest
 // ---- pair combine forward: one wave per edge row --------------------------------
 // pre[e,:] = Pa[i,:] + Pb[j,:] + delta*wd ; also LayerNorm stats of the row (the
 // wave already holds it) and delta.
+// Each wave walks EPW consecutive edge rows: the per-column constants (distance weight, gamma, beta) are loaded once,
+// and consecutive edges share their first vertex i (lexicographic order), so the Pa row stays in registers until i
+// changes.
 template <int NS>
 __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__ Pa, const float* __restrict__ Pb,
                                                         const float* __restrict__ cv, const float* __restrict__ wd,
@@ -63,78 +66,98 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int act, uint32_t seed, uint32_t thresh, float dscale,
                                                         float* __restrict__ h_sx8) {
+    constexpr int EPW = 8;
     const int lane = threadIdx.x & 63;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= Re) return;
-    const int s = esample[e];
-    const int v = voff[s + 1] - voff[s];
+    const int e0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW;
+    if (e0 >= Re) return;
+    const int e1 = min(Re, e0 + EPW);
+    f32x4 wdv[NS], g4[NS], b4[NS], pa[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int c = lane * 4 + 256 * t;
+        wdv[t] = g4[t] = b4[t] = pa[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < H) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wdv[t][k] = wd[(size_t)(c + k) * wd_stride];
+            if (h_sx8) { g4[t] = *reinterpret_cast<const f32x4*>(gamma + c); b4[t] = *reinterpret_cast<const f32x4*>(beta + c); }
+        }
+    }
+    int s = esample[e0], vbase = voff[s], v = voff[s + 1] - vbase, eend = eoff[s + 1];
     int i, j;
-    edge_ij(e - eoff[s], v, i, j);
-    const int ri = voff[s] + i, rj = voff[s] + j;
-    const float dx = cv[ri * 3] - cv[rj * 3], dy = cv[ri * 3 + 1] - cv[rj * 3 + 1], dz = cv[ri * 3 + 2] - cv[rj * 3 + 2];
-    const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
-    f32x4 val[NS];
-    float sum = 0.f;
+    edge_ij(e0 - eoff[s], v, i, j);
+    int pa_row = -1;
+    for (int e = e0; e < e1; ++e) {
+        if (e == eend) {                       // first edge of the next sample that has edges
+            s = esample[e]; vbase = voff[s]; v = voff[s + 1] - vbase; eend = eoff[s + 1];
+            i = 0; j = 1;
+        }
+        const int ri = vbase + i, rj = vbase + j;
+        const float dx = cv[ri * 3] - cv[rj * 3], dy = cv[ri * 3 + 1] - cv[rj * 3 + 1], dz = cv[ri * 3 + 2] - cv[rj * 3 + 2];
+        const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+        f32x4 val[NS];
+        float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const int c = lane * 4 + 256 * t;
-        val[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (c < H) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(Pa + (size_t)ri * H + c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(Pb + (size_t)rj * H + c);
+        for (int t = 0; t < NS; ++t) {
+            const int c = lane * 4 + 256 * t;
+            val[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < H) {
+                if (ri != pa_row) pa[t] = *reinterpret_cast<const f32x4*>(Pa + (size_t)ri * H + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Pb + (size_t)rj * H + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                val[t][k] = a[k] + b[k] + dl * wd[(size_t)(c + k) * wd_stride];
-                sum += val[t][k];
+                for (int k = 0; k < 4; ++k) {
+                    val[t][k] = pa[t][k] + b[k] + dl * wdv[t][k];
+                    sum += val[t][k];
+                }
+                *reinterpret_cast<f32x4*>(pre + (size_t)e * H + c) = val[t];
             }
-            *reinterpret_cast<f32x4*>(pre + (size_t)e * H + c) = val[t];
         }
-    }
-    const float mean = wf3d_wave_sum(sum) / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const int c = lane * 4 + 256 * t;
-        if (c < H) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const float d = val[t][k] - mean; q += d * d; }
-        }
-    }
-    const float var = wf3d_wave_sum(q) / (float)H;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (lane == 0) {
-        mu[e] = mean;
-        rs[e] = rstd;
-        delta[e] = dl;
-    }
-    // h = drop(act(LN(pre))) as the sx8 operand of the next Linear, from the row the wave still holds
-    // (what wf3d_ln_prep would produce from a second read of pre; same dropout counter: row e, column c).
-    if (h_sx8) {
+        pa_row = ri;
+        const float mean = wf3d_wave_sum(sum) / (float)H;
+        float q = 0.f;
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int c = lane * 4 + 256 * t;
             if (c < H) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c), b4 = *reinterpret_cast<const f32x4*>(beta + c);
-                float o[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    o[k] = wf3d_act_rt(act, (val[t][k] - mean) * rstd * g4[k] + b4[k]);
-                    if (thresh) o[k] = wf3d_keep(seed, (uint32_t)e, (uint32_t)(c + k), thresh) ? o[k] * dscale : 0.f;
-                }
-                // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts, odd lane the 8 low parts
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 hi, lo;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { hi[k] = (__bf16)o[k]; lo[k] = (__bf16)(o[k] - (float)hi[k]); }
-                const uint2 mine_hi = __builtin_bit_cast(uint2, hi), mine_lo = __builtin_bit_cast(uint2, lo);
-                const bool odd = lane & 1;
-                uint2 send = odd ? mine_hi : mine_lo, got;
-                got.x = __shfl_xor((int)send.x, 1, 64);
-                got.y = __shfl_xor((int)send.y, 1, 64);
-                const uint4 w = odd ? make_uint4(got.x, got.y, mine_lo.x, mine_lo.y) : make_uint4(mine_hi.x, mine_hi.y, got.x, got.y);
-                *reinterpret_cast<uint4*>(h_sx8 + (size_t)e * H + (c & ~7) + (odd ? 4 : 0)) = w;
+                for (int k = 0; k < 4; ++k) { const float d = val[t][k] - mean; q += d * d; }
             }
         }
+        const float var = wf3d_wave_sum(q) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (lane == 0) {
+            mu[e] = mean;
+            rs[e] = rstd;
+            delta[e] = dl;
+        }
+        // h = drop(act(LN(pre))) as the sx8 operand of the next Linear, from the row the wave still holds
+        // (what wf3d_ln_prep would produce from a second read of pre; same dropout counter: row e, column c).
+        if (h_sx8) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int c = lane * 4 + 256 * t;
+                if (c < H) {
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o[k] = wf3d_act_rt(act, (val[t][k] - mean) * rstd * g4[t][k] + b4[t][k]);
+                        if (thresh) o[k] = wf3d_keep(seed, (uint32_t)e, (uint32_t)(c + k), thresh) ? o[k] * dscale : 0.f;
+                    }
+                    // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts, odd lane the 8 low parts
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { hi[k] = (__bf16)o[k]; lo[k] = (__bf16)(o[k] - (float)hi[k]); }
+                    const uint2 mine_hi = __builtin_bit_cast(uint2, hi), mine_lo = __builtin_bit_cast(uint2, lo);
+                    const bool odd = lane & 1;
+                    uint2 send = odd ? mine_hi : mine_lo, got;
+                    got.x = __shfl_xor((int)send.x, 1, 64);
+                    got.y = __shfl_xor((int)send.y, 1, 64);
+                    const uint4 w = odd ? make_uint4(got.x, got.y, mine_lo.x, mine_lo.y) : make_uint4(mine_hi.x, mine_hi.y, got.x, got.y);
+                    *reinterpret_cast<uint4*>(h_sx8 + (size_t)e * H + (c & ~7) + (odd ? 4 : 0)) = w;
+                }
+            }
+        }
+        if (++j == v) { ++i; j = i + 1; }
     }
 }
 
@@ -327,7 +350,7 @@ static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, cons
     const int ns = wf3d_cdiv(H, 256);
     hipStream_t st = (hipStream_t)stream;
 #define WF3D_PF(NS_)                                                                                                 \
-    hipLaunchKernelGGL((pair_fwd_kernel<NS_>), dim3(wf3d_cdiv(Re, 4)), dim3(256), 0, st, Pa, Pb, cv, wdelta,           \
+    hipLaunchKernelGGL((pair_fwd_kernel<NS_>), dim3(wf3d_cdiv(Re, 4 * 8)), dim3(256), 0, st, Pa, Pb, cv, wdelta,           \
                        wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, gamma, beta, act, drop_seed,    \
                        thresh, dscale, (float*)h_sx8)
     if (ns <= 1) WF3D_PF(1); else if (ns <= 2) WF3D_PF(2); else if (ns <= 4) WF3D_PF(4); else WF3D_PF(8);
