@@ -202,12 +202,13 @@ def main():
     reducer = wd.GradReducer(model) if world > 1 else None
     x, counts, cot = make_inputs(B, N, V, rank, device)
     inv = 1.0 / (B * world)
+    keys = list(cot)
+    cots = [cot[k] * inv for k in keys]      # d/dtheta of loss = sum_k <out_k, c_k> / B_global, fed to autograd directly
 
     def step():
         model.zero_grad(set_to_none=True)
         out = model(x, counts)
-        loss = sum((out[k] * cot[k]).sum() for k in cot) * inv
-        loss.backward()
+        torch.autograd.backward([out[k] for k in keys], cots)
         if reducer is not None:
             reducer.finish()
 
