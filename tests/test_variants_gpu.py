@@ -1,4 +1,4 @@
-"""The split-GEMM kernels kept as selectable, measured baselines (WF3D_SPLIT_DMA = 2..6, WF3D_TN16 = 0/1: DESIGN.md §4)
+"""The split-GEMM kernels kept as selectable, measured baselines (WF3D_SPLIT_DMA = 2..7, WF3D_TN16 = 0/1: DESIGN.md §4)
 must stay correct.  The selection is read once per process, so each variant runs tests/variant_check.py in a
 child process (one at a time)."""
 import os
@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("env", [{"WF3D_SPLIT_DMA": "2"}, {"WF3D_SPLIT_DMA": "3"}, {"WF3D_SPLIT_DMA": "4"},
-                                 {"WF3D_SPLIT_DMA": "5"}, {"WF3D_SPLIT_DMA": "6"}, {"WF3D_TN16": "0"},
+                                 {"WF3D_SPLIT_DMA": "5"}, {"WF3D_SPLIT_DMA": "6"}, {"WF3D_SPLIT_DMA": "7"}, {"WF3D_TN16": "0"},
                                  {"WF3D_SPLIT_DMA": "0"}])
 def test_selectable_split_gemm_kernels(env):
     e = dict(os.environ)

@@ -1084,6 +1084,142 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// 128x128x32 tile on v_mfma_f32_16x16x32_bf16, 4 waves (2 x 2, 64x64 each = 4 x 4 accumulator tiles), two 32 KB
+// stages = 64 KB of LDS and <= 128 VGPRs: TWO workgroups per CU with independent phases, so one's C write-out
+// and slice-top latencies run under the other's MFMAs.  (The 256x256 kernel owns its CU alone: in-kernel stamps
+// put its write-out at 15-40 % of a tile's time.)  Price: twice the L2->LDS bytes per FLOP.
+// ---------------------------------------------------------------------------
+constexpr int S7_T = 128 * SBK, S7_STAGE = 2 * S7_T;
+
+__global__ __launch_bounds__(256, 2) void gemm_split_x16s_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * S7_STAGE];      // 65,536 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / p.nbn) * 128, n0 = (vid % p.nbn) * 128;
+    const int ktotal = p.K / SBK;
+    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
+
+    const float* asrc[4];
+    const float* bsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = ((lane & 7) ^ swz16(row)) * 4;
+        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
+        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fs = swz16(r16);
+    const int c_hi = ((2 * g) ^ fs) * 4, c_lo = ((2 * g + 1) ^ fs) * 4;
+    const int a_row = (wm * 64 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
+    {
+        float* dA = smem + wave * 4 * 8 * SBK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dma16_asm(asrc[q] + kt0 * SBK, dA + q * 8 * SBK);
+            dma16_asm(bsrc[q] + kt0 * SBK, dA + S7_T + q * 8 * SBK);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        float* dA = smem + (stage ^ 1) * S7_STAGE + wave * 4 * 8 * SBK;
+        float* dB = dA + S7_T;
+        const int kn = min(kt + 1, kt1 - 1) * SBK;                          // branch-free: last slice re-fetches itself
+        const float* As = smem + stage * S7_STAGE + a_row;
+        const float* Bs = smem + stage * S7_STAGE + S7_T + b_row;
+        f32x4 bh[4], bl[4], ah, al, ahn, aln;
+        al = *reinterpret_cast<const f32x4*>(As + c_lo);
+        bh[0] = *reinterpret_cast<const f32x4*>(Bs + c_hi);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_hi);
+        __builtin_amdgcn_sched_barrier(0);
+        ah = *reinterpret_cast<const f32x4*>(As + c_hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_lo);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < 3) {
+                ahn = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_hi);
+                aln = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_lo);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 2) { dma16_asm(asrc[2 * i] + kn, dA + (2 * i) * 8 * SBK);         dma16_asm(asrc[2 * i + 1] + kn, dA + (2 * i + 1) * 8 * SBK); }
+            else       { dma16_asm(bsrc[2 * i - 4] + kn, dB + (2 * i - 4) * 8 * SBK); dma16_asm(bsrc[2 * i - 3] + kn, dB + (2 * i - 3) * 8 * SBK); }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), val, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), vah, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ah = ahn; al = aln;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage ^= 1;
+    }
+
+    const bool split = p.ksplit > 1;
+    const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
+    const int colw = n0 + wn * 64 + g * 4;
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!split && p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = colw + j * 16 + e < p.N ? p.bias[colw + j * 16 + e] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + r16;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = colw + j * 16;
+            if (col >= p.N) continue;
+            f32x4 v = acc[i][j];
+            float* c = split ? p.slab + ((size_t)blockIdx.z * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
+            if (!split) v += bv[j];
+            if (vec && col + 3 < p.N) {
+                if (!split && p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+                *reinterpret_cast<f32x4*>(c) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= p.N) break;
+                    float o = v[e];
+                    if (!split && p.accumulate) o += c[e];
+                    c[e] = o;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
     const size_t total = (size_t)p.M * p.N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -1099,18 +1235,18 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) 
 
 // Kernel choice.  WF3D_SPLIT_DMA forces one: 2 = 128x128 2-stage, 3 = 256x128 3-stage,
 // 4 = 256x256 2-stage (32x32x16 MFMA), 5 = 256x256 4-stage k16 register-pipelined, 6 = 256x256
-// 2-stage on 16x16x32 MFMA.  Default (unset): 6 when the output has >= 512 such tiles (the tall
+// 2-stage on 16x16x32 MFMA, 7 = 128x128 two-workgroups-per-CU on 16x16x32 (measured 20 % slower than 6).  Default (unset): 6 when the output has >= 512 such tiles (the tall
 // forward / dgrad GEMMs), else 3 (few tiles, long split-K reductions).  Measured on the encoder
 // shapes, same process: 6 is 11-14 % faster than 4; 5 equals 4 with its DMA issued early (+5 %).
 int split_variant(int M, int N) {
     static const int forced = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 6) return forced;
+    if (forced >= 2 && forced <= 7) return forced;
     return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= 512 ? 6 : 3;
 }
 
 void plan(int M, int N, int K, int& ksplit, int& kt_per) {
     const int v = split_variant(M, N);
-    const int bm = v >= 3 ? 256 : 128, bn = v >= 4 ? 256 : 128;
+    const int bm = (v >= 3 && v != 7) ? 256 : 128, bn = (v >= 4 && v != 7) ? 256 : 128;
     const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, bn);
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
@@ -1150,13 +1286,14 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
     const int variant = split_variant(M, N);
     const bool deep = variant == 3;
-    p.nbm = wf3d_cdiv(M, variant >= 3 ? 256 : 128); p.nbn = wf3d_cdiv(N, variant >= 4 ? 256 : 128);
+    p.nbm = wf3d_cdiv(M, (variant >= 3 && variant != 7) ? 256 : 128); p.nbn = wf3d_cdiv(N, (variant >= 4 && variant != 7) ? 256 : 128);
     plan(M, N, K, p.ksplit, p.kt_per_split);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 6) hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    if (variant == 7) hipLaunchKernelGGL(gemm_split_x16s_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
+    else if (variant == 6) hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (variant == 5) hipLaunchKernelGGL(gemm_split_p4_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
