@@ -287,6 +287,9 @@ int wf3d_loss_cost_matrix(const float* verts, long sample_stride, long vertex_st
  * .cpu().numpy() sync of WireframeLoss.py:235-236.  col4row[b,p] = column of prediction p;
  * p is matched to a real target iff col4row[b,p] < counts[b]. */
 int wf3d_loss_assign(const float* cost, int B, int V, int32_t* col4row, void* stream);
+/* Same result for the wireframe cost (dummy columns >= counts[b] identical per row): solves the count x V rectangular
+ * problem "real targets -> distinct predictions, cost c[p,t] - e_p" instead of the padded square one (V <= 64). */
+int wf3d_loss_assign_counts(const float* cost, const int64_t* counts, int B, int V, int32_t* col4row, void* stream);
 int wf3d_loss_terms_assigned(const float* verts, long sample_stride, long vertex_stride, const float* exist,
                              const float* edge, int Ep, const float* tverts, int Vt, const float* texist,
                              const float* tlabel, int Et, const int32_t* col4row, const int64_t* counts, int B, int V,

@@ -6,7 +6,7 @@ import torch
 from wf3d import ops
 from losses.WireframeLoss import WireframeLoss
 dev = torch.device("cuda:0")
-B, V = 32, 64
+B, V = 32, int(os.environ.get("V", 64))
 E = V * (V - 1) // 2
 torch.manual_seed(0)
 pv = torch.randn(B, V, 4, device=dev)[:, :, :3].requires_grad_()

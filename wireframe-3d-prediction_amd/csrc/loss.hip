@@ -199,16 +199,29 @@ __device__ __forceinline__ double lane_read_f64(double x, int lane_uniform) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(64) void lsa64_kernel(const float* __restrict__ cost, int V, int32_t* __restrict__ col4row_out) {
+// RECT (counts given): the wireframe cost has V - count identical dummy columns (cost e_p for prediction p), so the
+// square problem equals the rectangular one "assign each of the count real targets to a distinct prediction, cost
+// c[p,t] - e_p" (+ a constant): rows = targets, lane = prediction, only `count` augmentations instead of V (the
+// dataset's counts are 4..38 of 64).  Unmatched predictions get the dummy columns count, count+1, ... in lane order.
+template <bool RECT>
+__global__ __launch_bounds__(64) void lsa64_kernel(const float* __restrict__ cost, const int64_t* __restrict__ counts, int V,
+                                                    int32_t* __restrict__ col4row_out) {
     __shared__ float Cs[64 * 64];
     const int lane = threadIdx.x, b = blockIdx.x;
     const float* C = cost + (size_t)b * V * V;
-    for (int idx = lane; idx < V * V; idx += 64) Cs[idx] = C[idx];
-    __syncthreads();
+    const int nrow = RECT ? min((int)counts[b], V) : V;
     const bool col_ok = lane < V;
+    double ep = 0.0;
+    if (RECT) {
+        for (int idx = lane; idx < nrow * V; idx += 64) Cs[idx] = C[(size_t)(idx % V) * V + idx / V];      // Cs[t][p] = cost[p][t]
+        if (col_ok && nrow < V) ep = (double)C[(size_t)lane * V + V - 1];
+    } else {
+        for (int idx = lane; idx < V * V; idx += 64) Cs[idx] = C[idx];
+    }
+    __syncthreads();
     double u = 0.0, v = 0.0;
     int row4col = -1, col4row = -1;
-    for (int cur = 0; cur < V; ++cur) {
+    for (int cur = 0; cur < nrow; ++cur) {
         double spc = INFINITY;
         bool in_sc = !col_ok;
         int path = -1;
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(64) void lsa64_kernel(const float* __restrict__ cos
             sr_mask |= 1ull << i;
             const double ui = lane_read_f64(u, i);
             if (!in_sc) {
-                const double r = min_val + (double)Cs[i * V + lane] - ui - v;
+                const double r = min_val + ((double)Cs[i * V + lane] - ep) - ui - v;
                 if (r < spc) { spc = r; path = i; }
             }
             double m = in_sc ? INFINITY : spc;
@@ -251,7 +264,14 @@ __global__ __launch_bounds__(64) void lsa64_kernel(const float* __restrict__ cos
             j = __builtin_amdgcn_readfirstlane(prev);
         }
     }
-    if (col_ok) col4row_out[(size_t)b * V + lane] = col4row;
+    if (RECT) {
+        // lane = prediction: its target, or the next free dummy column
+        const unsigned long long un = __ballot(col_ok && row4col < 0);
+        const int rank = __builtin_popcountll(un & ((1ull << lane) - 1ull));
+        if (col_ok) col4row_out[(size_t)b * V + lane] = row4col >= 0 ? row4col : nrow + rank;
+    } else if (col_ok) {
+        col4row_out[(size_t)b * V + lane] = col4row;
+    }
 }
 
 // loss terms from the device assignment: prediction p of sample b is matched iff col4row[b,p] < count[b]
@@ -359,7 +379,7 @@ extern "C" int wf3d_loss_assign(const float* cost, int B, int V, int32_t* col4ro
     if (B == 0) return WF3D_OK;
     WF3D_CHECK(cost && col4row, WF3D_ERR_ARG, "wf3d_loss_assign: null pointer");
     if (V <= 64) {
-        hipLaunchKernelGGL(lsa64_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cost, V, col4row);
+        hipLaunchKernelGGL(lsa64_kernel<false>, dim3(B), dim3(64), 0, (hipStream_t)stream, cost, (const int64_t*)nullptr, V, col4row);
     } else {
         const size_t lds = (size_t)V * (3 * sizeof(double) + 4 * sizeof(int) + 1) + 16;
         hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, cost, V, col4row);
@@ -389,6 +409,16 @@ extern "C" int wf3d_loss_terms_assigned(const float* verts, long sample_stride, 
     WF3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_dev_kernel, dim3(1), dim3(1), 0, st, (const float*)ws, counts, B, V, ne, nd, w_vertex,
                        w_exist, w_edge, losses);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_loss_assign_counts(const float* cost, const int64_t* counts, int B, int V, int32_t* col4row, void* stream) {
+    WF3D_CHECK(B >= 0 && V > 0, WF3D_ERR_ARG, "wf3d_loss_assign_counts: bad dims");
+    if (B == 0) return WF3D_OK;
+    WF3D_CHECK(cost && counts && col4row, WF3D_ERR_ARG, "wf3d_loss_assign_counts: null pointer");
+    if (V > 64) return wf3d_loss_assign(cost, B, V, col4row, stream);       // general kernel: square problem
+    hipLaunchKernelGGL(lsa64_kernel<true>, dim3(B), dim3(64), 0, (hipStream_t)stream, cost, counts, V, col4row);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

@@ -21,6 +21,8 @@ class _LossDevFn(torch.autograd.Function):
     def forward(ctx, verts, exist, edge, tverts, texist, tlabel, counts, weights):
         exist_c = exist.contiguous()
         cost = ops.loss_cost_matrix(verts, exist_c, tverts, counts)
+        # the square problem, rows in prediction order like scipy: L1 costs have exact ties (2 of 32 random samples
+        # at V = 64) and the rectangular shortcut of ops.loss_assign(cost, counts) resolves them differently
         col4row = ops.loss_assign(cost)
         losses, dv, de, dd = ops.loss_terms_assigned(verts, exist_c, edge.contiguous(), tverts, texist, tlabel,
                                                      col4row, counts, weights)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "wf3d_loss_cost_matrix": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                       c_int, c_void_p, c_void_p]),
     "wf3d_loss_assign": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_loss_assign_counts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_loss_terms_assigned": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p,
                                          c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
                                          c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -633,12 +633,17 @@ def loss_terms(verts, exist, edge, tverts, texist, tlabel, m_pred, m_tgt, m_off,
     return losses, dverts, dexist, dedge
 
 
-def loss_assign(cost):
-    """cost [B,V,V] -> col4row int32 [B,V]: optimal assignment per sample, computed on the device."""
-    _need_cuda(cost)
+def loss_assign(cost, counts=None):
+    """cost [B,V,V] -> col4row int32 [B,V]: optimal assignment per sample, computed on the device.  With `counts`
+    (int64 [B]; columns >= counts[b] are the wireframe cost's identical dummy columns) only the real targets are
+    augmented: same matches to real targets, unmatched predictions on the dummy columns in order."""
+    _need_cuda(cost, counts)
     B, V, _ = cost.shape
     out = torch.empty(B, V, dtype=torch.int32, device=cost.device)
-    check(_lib.load().wf3d_loss_assign(_p(cost), B, V, _p(out), _stream()), "loss_assign")
+    if counts is None:
+        check(_lib.load().wf3d_loss_assign(_p(cost), B, V, _p(out), _stream()), "loss_assign")
+    else:
+        check(_lib.load().wf3d_loss_assign_counts(_p(cost), _p(counts), B, V, _p(out), _stream()), "loss_assign_counts")
     return out
 
 
