@@ -51,6 +51,7 @@ struct SplitParams {
     int ksplit, kt_per_split;
     float* slab;
     int nbm, nbn;
+    int zmap;          // x16 kernel, wgrad: 1 = 1-D grid of tiles x ksplit blocks, XCD k owns the split-K ranges z = k (mod 8)
 };
 
 __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
@@ -883,10 +884,22 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
     const int nwg = p.nbm * p.nbn;
     const int bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int vid, zi;
+    if (p.zmap) {
+        // wgrad: every tile of one split-K range z reads the same rows of both operands.  Workgroups are dealt to the
+        // XCDs round-robin, so give XCD k the ranges z = k, k + 8, ... with ALL their tiles: each operand slice is then
+        // fetched into one L2 once and shared there (A by the nbn tiles of its row, B by the nbm tiles of its column)
+        // instead of every XCD streaming the whole B operand (measured: 3.06 GB fetched per launch for 1.2 GB of operands).
+        const int q = bid >> 3;
+        vid = q % nwg;
+        zi = (q / nwg) * 8 + xcd;
+    } else {
+        vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        zi = blockIdx.z;
+    }
     const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 256;
     const int ktotal = p.K / SBK;
-    const int kt0 = blockIdx.z * p.kt_per_split;
+    const int kt0 = zi * p.kt_per_split;
     const int kt1 = min(ktotal, kt0 + p.kt_per_split);
 
     // DMA sources: 4 A pieces + 4 B pieces of 1 KB per wave and slice.  NT: a piece = 8 tile rows x 128 B;
@@ -1053,7 +1066,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             const int col = colw + j * 16;
             if (col >= p.N) continue;
             f32x4 v = acc[i][j];
-            float* c = split ? p.slab + ((size_t)blockIdx.z * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
+            float* c = split ? p.slab + ((size_t)zi * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
             if (!split) v += bv[j];
             if (WF3D_ABLATE == 3 && v[0] != 1234.5f) continue;       // timing-only: no C stores
             if (vec && col + 3 < p.N) {
@@ -1361,7 +1374,11 @@ extern "C" int wf3d_gemm_split_tn(const void* A_sx8, const void* B_sx8, float* C
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (big) hipLaunchKernelGGL(gemm_split_x16_kernel<true>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    static const int zmap_off = [] { const char* e = getenv("WF3D_TN_ZMAP"); return e && atoi(e) == 0; }();
+    if (big && !zmap_off && p.ksplit >= 8 && p.ksplit % 8 == 0) {
+        p.zmap = 1;
+        hipLaunchKernelGGL(gemm_split_x16_kernel<true>, dim3(p.nbm * p.nbn * p.ksplit, 1, 1), dim3(512), 0, st, p);
+    } else if (big) hipLaunchKernelGGL(gemm_split_x16_kernel<true>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else     hipLaunchKernelGGL(gemm_split_tn_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
