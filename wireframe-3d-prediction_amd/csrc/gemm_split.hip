@@ -1098,6 +1098,155 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 }
 
 // ---------------------------------------------------------------------------
+// Persistent form of the forward / dgrad kernel above (full tiles, no split-K): one workgroup per CU walks its
+// XCD's tiles slot, slot + S, ... and treats their k-slices as ONE stream — the last slices of a tile already DMA
+// the first A / B slices of the next, so a tile starts without the cold-miss prologue and without a workgroup
+// launch; its C stores drain behind the next tile's first slice (they are older than that slice's DMA pieces in
+// the in-order vmcnt queue, so the slice-end wait also retires them).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[5 * T4_A];          // 163,840 B: A x 3 stages, B x 2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    const int nwg = p.nbm * p.nbn;
+    const int bid = blockIdx.x, S = gridDim.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcnt = xcd < r8 ? q8 + 1 : q8;
+    if (slot >= xcnt) return;
+    const int ntile = (xcnt - slot + S - 1) / S;
+    const int ktotal = p.K / SBK;                                          // >= 2 (host-checked)
+
+    // per-lane offsets of the 4 A and 4 B pieces inside a tile (full tiles only: no row clamping)
+    size_t aoff[4], boff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + (lane >> 3);
+        const int chunk = ((lane & 7) ^ swz16(row)) * 4;
+        aoff[q] = (size_t)row * p.lda + chunk;
+        boff[q] = (size_t)row * p.ldb + chunk;
+    }
+    auto tile_m0 = [&](int t) { return ((xbase + slot + t * S) / p.nbn) * 256; };
+    auto tile_n0 = [&](int t) { return ((xbase + slot + t * S) % p.nbn) * 256; };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fs = swz16(r16);
+    const int c_hi = ((2 * g) ^ fs) * 4, c_lo = ((2 * g + 1) ^ fs) * 4;
+    const int a_row = (wm * 128 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
+    float* const smemB = smem + 3 * T4_A;
+
+    const float* Acur = p.A + (size_t)tile_m0(0) * p.lda;                  // scalar bases of the current / next tile
+    const float* Bcur = p.B + (size_t)tile_n0(0) * p.ldb;
+    {   // prologue of the whole stream: A(0), B(0), A(1) of the first tile
+        float* dA = smem + wave * 4 * 8 * SBK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_asm(Acur + aoff[q], dA + q * 8 * SBK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_asm(Bcur + boff[q], smemB + wave * 4 * 8 * SBK + q * 8 * SBK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma16_asm(Acur + aoff[q] + SBK, dA + T4_A + q * 8 * SBK);
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int stage = 0, astage = 0;
+    const bool vec = p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0);
+    for (int t = 0; t < ntile; ++t) {
+        const bool has_next = t + 1 < ntile;
+        const float* Anext = has_next ? p.A + (size_t)tile_m0(t + 1) * p.lda : Acur;
+        const float* Bnext = has_next ? p.B + (size_t)tile_n0(t + 1) * p.ldb : Bcur;
+        for (int kt = 0; kt < ktotal; ++kt) {
+            const int astage2 = astage == 0 ? 2 : astage - 1;
+            float* dA = smem + astage2 * T4_A + wave * 4 * 8 * SBK;            // A(s+2)
+            float* dB = smemB + (stage ^ 1) * T4_A + wave * 4 * 8 * SBK;       // B(s+1)
+            // where slices s+1 / s+2 of the stream live: this tile, the next one, or (at the very end) a harmless re-fetch
+            const bool b_here = kt + 1 < ktotal, a_here = kt + 2 < ktotal;
+            const float* Bsrc = b_here ? Bcur : Bnext;
+            const float* Asrc = a_here ? Acur : Anext;
+            const int kb_i = b_here ? kt + 1 : (has_next ? 0 : ktotal - 1);
+            const int ka_i = a_here ? kt + 2 : (has_next ? kt + 2 - ktotal : ktotal - 1);
+            const float* Bp = Bsrc + (size_t)kb_i * SBK;
+            const float* Ap = Asrc + (size_t)ka_i * SBK;
+            const float* As = smem + astage * T4_A;
+            const float* Bs = smemB + stage * T4_A;
+            f32x4 bh[4], bl[4], ah, al, ahn, aln;
+            al = *reinterpret_cast<const f32x4*>(As + a_row + c_lo);
+            bh[0] = *reinterpret_cast<const f32x4*>(Bs + b_row + c_hi);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + c_hi);
+            __builtin_amdgcn_sched_barrier(0);
+            ah = *reinterpret_cast<const f32x4*>(As + a_row + c_hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + c_lo);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < 7) {
+                    ahn = *reinterpret_cast<const f32x4*>(As + a_row + (i + 1) * 16 * SBK + c_hi);
+                    aln = *reinterpret_cast<const f32x4*>(As + a_row + (i + 1) * 16 * SBK + c_lo);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 4) {      // B(s+1) first, A(s+2) last: the slice-end wait skips exactly the 4 youngest
+                    if (i < 2) { dma16_asm(Bp + boff[2 * i], dB + (2 * i) * 8 * SBK);         dma16_asm(Bp + boff[2 * i + 1], dB + (2 * i + 1) * 8 * SBK); }
+                    else       { dma16_asm(Ap + aoff[2 * i - 4], dA + (2 * i - 4) * 8 * SBK); dma16_asm(Ap + aoff[2 * i - 3], dA + (2 * i - 3) * 8 * SBK); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), val, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), vah, acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ah = ahn; al = aln;
+            }
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage ^= 1;
+            astage = astage == 2 ? 0 : astage + 1;
+        }
+        // ---- C of tile t (its first slices of tile t+1 are already in LDS / in flight) ----
+        const int m0 = tile_m0(t), n0 = tile_n0(t);
+        const int colw = n0 + wn * 64 + g * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + wm * 128 + i * 16 + r16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = colw + j * 16;
+                f32x4 v = acc[i][j];
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.bias[col + e];
+                }
+                float* c = p.C + (size_t)row * p.ldc + col;
+                if (vec) {
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+                    *reinterpret_cast<f32x4*>(c) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c[e] = p.accumulate ? c[e] + v[e] : v[e];
+                }
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        Acur = Anext; Bcur = Bnext;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
+}
+
+// ---------------------------------------------------------------------------
 // 128x128x32 tile on v_mfma_f32_16x16x32_bf16, 4 waves (2 x 2, 64x64 each = 4 x 4 accumulator tiles), two 32 KB
 // stages = 64 KB of LDS and <= 128 VGPRs: TWO workgroups per CU with independent phases, so one's C write-out
 // and slice-top latencies run under the other's MFMAs.  (The 256x256 kernel owns its CU alone: in-kernel stamps
@@ -1251,6 +1400,16 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) 
 // 2-stage on 16x16x32 MFMA, 7 = 128x128 two-workgroups-per-CU on 16x16x32 (measured 20 % slower than 6).  Default (unset): 6 when the output has >= 512 such tiles (the tall
 // forward / dgrad GEMMs), else 3 (few tiles, long split-K reductions).  Measured on the encoder
 // shapes, same process: 6 is 11-14 % faster than 4; 5 equals 4 with its DMA issued early (+5 %).
+int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return v;
+    }();
+    return n;
+}
+
 int split_variant(int M, int N) {
     static const int forced = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 0; }();
     if (forced >= 2 && forced <= 7) return forced;
@@ -1306,7 +1465,15 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (variant == 7) hipLaunchKernelGGL(gemm_split_x16s_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
-    else if (variant == 6) hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    else if (variant == 6) {
+        static const int persist_on = [] { const char* e = getenv("WF3D_SPLIT_PERSIST"); return e ? atoi(e) : 1; }();
+        const int cus = cu_count();
+        if (persist_on && p.ksplit == 1 && M % 256 == 0 && N % 256 == 0 && K / SBK >= 2 && cus >= 8 && cus % 8 == 0 &&
+            p.nbm * p.nbn >= 2 * cus)
+            hipLaunchKernelGGL(gemm_split_x16p_kernel, dim3(cus, 1, 1), dim3(512), 0, st, p);
+        else
+            hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    }
     else if (variant == 5) hipLaunchKernelGGL(gemm_split_p4_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     else if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
