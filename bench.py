@@ -89,7 +89,7 @@ class GemmTimer:
     def install(self, ops, split):
         self._ops, self._orig = ops, (ops.gemm, ops.gemm_split)
         if split:
-            # dominant kernel = gemm_split_x16_kernel: the 8 forward + dgrad GEMMs of the per-point MLP
+            # dominant kernel = gemm_split_x16p_kernel: the 8 forward + dgrad GEMMs of the per-point MLP
             # (the 4 wgrad GEMMs run gemm_split_tn_kernel and are reported by rocprofv3 in profiles/)
             ops.gemm_split = self._wrap(ops.gemm_split, lambda a, b: (a.shape[0], b.shape[0], a.shape[1]))
         else:
@@ -246,7 +246,7 @@ def main():
                 traffic = None
         if split:
             # bf16x3: every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
-            peak, kern = BF16_MFMA_PEAK_TFLOPS, "gemm_split_x16_kernel (256x256x32 tile, LDS-DMA staged, 3 x v_mfma_f32_16x16x32_bf16 per product)"
+            peak, kern = BF16_MFMA_PEAK_TFLOPS, "gemm_split_x16p_kernel (persistent, 256x256x32 tile, LDS-DMA staged, 3 x v_mfma_f32_16x16x32_bf16 per product)"
             extra = {"executed_mfma_tflops": 3.0 * achieved, "executed_frac": 3.0 * achieved / peak,
                      "note": "achieved = algorithmic 2MNK FLOP / time; the split algorithm issues 3 MFMA FLOP per algorithmic FLOP"}
         else:

@@ -68,7 +68,7 @@ fetch, write, sq = pmc(f"prof_{tag}_fetch/**/*_counter_collection.csv"), \
     pmc(f"prof_{tag}_write/**/*_counter_collection.csv"), pmc(f"prof_{tag}_sq/**/*_counter_collection.csv")
 
 BIG_US = 300.0          # the encoder's twelve >=137-GFLOP GEMM launches per step all run > 0.35 ms
-DOM = os.environ.get("WF3D_DOMINANT", "gemm_split_x16_kernel<false>")   # dominant kernel (fp32 mode: "gemm_kernel<2, 2, 2, 2")
+DOM = os.environ.get("WF3D_DOMINANT", "gemm_split_x16p_kernel")   # dominant kernel (fp32 mode: "gemm_kernel<2, 2, 2, 2")
 
 
 def big(vals):
