@@ -495,3 +495,22 @@ def test_ln_act_bwd_with_weighted_column_sum(ops, R, D, drop):
     dz2, dg2, db2, wsum = ops.ln_act_bwd_wsum(dh.clone(), z, wrow, mu, rs, gamma, beta, ops.ACT_GELU, drop, 77)
     assert torch.equal(dz, dz2) and rel(dg, dg2) < 1e-6 and rel(db, db2) < 1e-6
     assert rel(wsum, (dz.double().cpu() * wrow.double().cpu()[:, None]).sum(0)) < 2e-5
+
+
+def test_split_gemms_accumulate_into_out_at_encoder_launch_shapes(ops):
+    """accumulate=True on the persistent forward/dgrad kernel (>= 512 full tiles) and on the XCD-mapped split-K wgrad
+    kernel: C += A·B^T / A^T·B on integer data, exact."""
+    M, N, K = 32768, 1024, 96
+    A = (torch.arange(M * K, device=dev()).reshape(M, K) % 7 - 3).float()
+    B = ((torch.arange(N * K, device=dev()).reshape(N, K) * 5) % 11 - 5).float()
+    out = (torch.arange(M * N, device=dev()).reshape(M, N) % 17 - 8).float()
+    want = out.double() + A.double() @ B.double().T
+    ops.gemm_split(ops.split_rows(A), ops.split_rows(B), out=out, accumulate=True)
+    assert torch.equal(out.double(), want)
+    Kt, Mo, No = 65536, 512, 256
+    At = (torch.arange(Kt * Mo, device=dev()).reshape(Kt, Mo) % 5 - 2).float()
+    Bt = ((torch.arange(Kt * No, device=dev()).reshape(Kt, No) * 3) % 7 - 3).float()
+    out2 = (torch.arange(Mo * No, device=dev()).reshape(Mo, No) % 9 - 4).float()
+    want2 = out2.double() + At.double().T @ Bt.double()
+    ops.gemm_split_tn(ops.split_rows(At), ops.split_rows(Bt), out=out2, accumulate=True)
+    assert torch.equal(out2.double(), want2)
