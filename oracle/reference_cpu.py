@@ -37,6 +37,25 @@ def _ln(P, name, x):
     return F.layer_norm(x, (w.shape[0],), w, P[name + ".bias"], LN_EPS)
 
 
+def _relu_ln(P, name, u, frozen=None):
+    """relu(LayerNorm(u)).  With `frozen` (decision-frozen mode, tests/test_frozen_grad_gpu.py) the
+    ReLU's 0/1 decision of LayerNorm `name` is not re-taken from this run's values but read from
+    frozen["relu"][name] (a bool tensor recorded from another run of the same network), so that the
+    result is a smooth function of the arithmetic: relu(v) -> v * mask."""
+    v = _ln(P, name, u)
+    if frozen is not None and name in frozen.get("relu", {}):
+        return v * frozen["relu"][name].to(v.dtype)
+    return torch.relu(v)
+
+
+def _max_over_points(pf, frozen, key, fill_dead=False):
+    """max over dim 1 of pf [B,N,C]; decision-frozen mode gathers the recorded arg-max rows
+    frozen["argmax"][key] ([B,C] int64, -1 = no valid row -> 0) instead of re-deciding them."""
+    idx = frozen["argmax"][key]
+    got = torch.gather(pf, 1, idx.clamp(min=0).unsqueeze(1)).squeeze(1)
+    return torch.where(idx >= 0, got, torch.zeros_like(got))
+
+
 def _count_blocks(P, prefix, stride):
     n = 0
     while f"{prefix}{stride * n}.weight" in P:
@@ -47,7 +66,7 @@ def _count_blocks(P, prefix, stride):
 # --------------------------------------------------------------------------
 # PointNetEncoder.forward  (reference models/PointNetEncoder.py:67-118)
 # --------------------------------------------------------------------------
-def encoder_point_mlp(P, x2d, prefix="encoder."):
+def encoder_point_mlp(P, x2d, prefix="encoder.", frozen=None):
     """Per-point shared MLP (reference PointNetEncoder.py:35-45,94): blocks of
     Linear -> LayerNorm -> ReLU at Sequential indices 4i, 4i+1, closed by a
     bare Linear at index 4*n_hidden."""
@@ -55,54 +74,60 @@ def encoder_point_mlp(P, x2d, prefix="encoder."):
     n_lin = _count_blocks(P, mp, 4)           # Linears sit at 0,4,8,...
     h = x2d
     for i in range(n_lin - 1):
-        h = torch.relu(_ln(P, f"{mp}{4 * i + 1}", _lin(P, f"{mp}{4 * i}", h)))
+        h = _relu_ln(P, f"{mp}{4 * i + 1}", _lin(P, f"{mp}{4 * i}", h), frozen)
     return _lin(P, f"{mp}{4 * (n_lin - 1)}", h)
 
 
-def encoder_pools(x, pf):
+def encoder_pools(x, pf, frozen=None):
     """Mask-aware pools (reference PointNetEncoder.py:85-86,103-111)."""
     valid = x.detach().abs().sum(-1) > 1e-9                       # [B,N]
     cnt = valid.sum(1, keepdim=True).clamp(min=1).to(pf.dtype)     # [B,1]
     avg = (pf * valid.unsqueeze(-1)).sum(1) / cnt
+    if frozen is not None and "enc_masked" in frozen.get("argmax", {}):
+        return _max_over_points(pf, frozen, "enc_masked"), avg
     neg = torch.full_like(pf, float("-inf"))
     mx = torch.where(valid.unsqueeze(-1), pf, neg).max(dim=1).values
     mx = torch.where(torch.isfinite(mx), mx, torch.zeros_like(mx))
     return mx, avg
 
 
-def encoder_fusion(P, pooled, prefix="encoder."):
+def encoder_fusion(P, pooled, prefix="encoder.", frozen=None):
     """feature_fusion (reference PointNetEncoder.py:57-65): Linear,LN,ReLU,
     Linear,LN,ReLU,Linear at Sequential indices 0,1,3,4,6."""
     fp = prefix + "feature_fusion."
-    h = torch.relu(_ln(P, fp + "1", _lin(P, fp + "0", pooled)))
-    h = torch.relu(_ln(P, fp + "4", _lin(P, fp + "3", h)))
+    h = _relu_ln(P, fp + "1", _lin(P, fp + "0", pooled), frozen)
+    h = _relu_ln(P, fp + "4", _lin(P, fp + "3", h), frozen)
     return _lin(P, fp + "6", h)
 
 
-def encoder_forward(P, x, prefix="encoder."):
+def encoder_forward(P, x, prefix="encoder.", frozen=None):
     B, N, D = x.shape
-    pf = encoder_point_mlp(P, x.reshape(B * N, D), prefix).reshape(B, N, -1)
-    mx, avg = encoder_pools(x, pf)
-    g = encoder_fusion(P, torch.cat([mx, avg], dim=1), prefix)     # max first (:115)
+    pf = encoder_point_mlp(P, x.reshape(B * N, D), prefix, frozen).reshape(B, N, -1)
+    mx, avg = encoder_pools(x, pf, frozen)
+    g = encoder_fusion(P, torch.cat([mx, avg], dim=1), prefix, frozen)     # max first (:115)
     return g, pf
 
 
 # --------------------------------------------------------------------------
 # VertexPredictor.forward  (reference models/VertexPredictor.py:63-133)
 # --------------------------------------------------------------------------
-def vertex_forward(P, g, pf, max_vertices, vertex_dim=4, prefix="vertex_predictor."):
+def vertex_forward(P, g, pf, max_vertices, vertex_dim=4, prefix="vertex_predictor.", frozen=None):
     if pf is not None:
         # UNMASKED mean/max over all N points, mean first (:86-88), through the
         # lazily created point_pool_proj (:94-99), added to the global vector.
-        pooled = torch.cat([pf.mean(dim=1), pf.max(dim=1).values], dim=1)
+        if frozen is not None and "vert_unmasked" in frozen.get("argmax", {}):
+            umax = _max_over_points(pf, frozen, "vert_unmasked")
+        else:
+            umax = pf.max(dim=1).values
+        pooled = torch.cat([pf.mean(dim=1), umax], dim=1)
         e = g + _lin(P, prefix + "point_pool_proj", pooled)
     else:
         e = g
-    a = torch.relu(_ln(P, prefix + "vertex_mlp1.1", _lin(P, prefix + "vertex_mlp1.0", e)))
-    b = torch.relu(_ln(P, prefix + "vertex_mlp2.1", _lin(P, prefix + "vertex_mlp2.0", a)))
-    c = torch.relu(_ln(P, prefix + "vertex_mlp3.1", _lin(P, prefix + "vertex_mlp3.0", b)))
+    a = _relu_ln(P, prefix + "vertex_mlp1.1", _lin(P, prefix + "vertex_mlp1.0", e), frozen)
+    b = _relu_ln(P, prefix + "vertex_mlp2.1", _lin(P, prefix + "vertex_mlp2.0", a), frozen)
+    c = _relu_ln(P, prefix + "vertex_mlp3.1", _lin(P, prefix + "vertex_mlp3.0", b), frozen)
     c = c + _lin(P, prefix + "residual_proj1", e)                 # residual after ReLU (:110)
-    d = torch.relu(_ln(P, prefix + "vertex_mlp4.1", _lin(P, prefix + "vertex_mlp4.0", c)))
+    d = _relu_ln(P, prefix + "vertex_mlp4.1", _lin(P, prefix + "vertex_mlp4.0", c), frozen)
     d = d + _lin(P, prefix + "residual_proj2", e)
     o = _lin(P, prefix + "final_layer", d).reshape(g.shape[0], max_vertices, vertex_dim)
     coords = o[:, :, :3]
@@ -177,9 +202,11 @@ def edge_forward(P, verts, num_heads=8, prefix="edge_predictor."):
 # --------------------------------------------------------------------------
 # PointCloudToWireframe.forward  (reference models/PointCloudToWireframe.py:43-121)
 # --------------------------------------------------------------------------
-def model_forward(P, x, target_vertex_counts, max_vertices, training=True, num_heads=8):
-    g, pf = encoder_forward(P, x)
-    vo = vertex_forward(P, g, pf, max_vertices)
+def model_forward(P, x, target_vertex_counts, max_vertices, training=True, num_heads=8, frozen=None):
+    """frozen: optional {"relu": {LayerNorm name: bool mask}, "argmax": {"enc_masked"|"vert_unmasked": [B,C]}}
+    — the piecewise-constant decisions of another run, see _relu_ln."""
+    g, pf = encoder_forward(P, x, frozen=frozen)
+    vo = vertex_forward(P, g, pf, max_vertices, frozen=frozen)
     verts = vo["vertices"]
     B = verts.shape[0]
     if training and target_vertex_counts is not None:
@@ -192,7 +219,8 @@ def model_forward(P, x, target_vertex_counts, max_vertices, training=True, num_h
         probs.append(p[0])
         indices.append(idx)
     max_e = max((len(p) for p in probs), default=0)
-    padded = torch.zeros(B, max_e, device=verts.device)            # always fp32 (:107)
+    # always fp32 in the reference (:107); the fp64 decision-frozen runs keep their own dtype
+    padded = torch.zeros(B, max_e, device=verts.device, dtype=torch.float32 if frozen is None else verts.dtype)
     for s, p in enumerate(probs):
         if len(p) > 0:
             padded[s, :len(p)] = p

@@ -71,6 +71,75 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def elem_err(a, b, floor=None):
+    """Element-wise relative error: max_i |a_i - b_i| / max(|b_i|, floor).
+
+    `floor` is the stated absolute floor below which an element's own magnitude stops being the
+    yardstick (a sum that cancels to ~0 cannot be reproduced to 1e-4 of itself by ANY other
+    summation order).  Default: the tensor's rms.  Probabilities pass floor=1e-6 so that small
+    tails are held to 1e-4 of their own value."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return float("inf")
+    if a.size == 0:
+        return 0.0
+    if floor is None:
+        floor = float(np.sqrt(np.mean(b * b)))
+    return float((np.abs(a - b) / np.maximum(np.abs(b), max(floor, 1e-300))).max())
+
+
+# floors for the forward outputs: probabilities are compared against their own value down to 1e-6
+OUT_FLOOR = {"existence_probabilities": 1e-6, "edge_probs": 1e-6, "vertices": None, "global_features": None}
+
+
+def out_errs(got, want, keys=("vertices", "existence_probabilities", "edge_probs", "global_features")):
+    """{key: (max-abs/max rel_err, element-wise elem_err)} for model output dicts of tensors."""
+    res = {}
+    for k in keys:
+        a = got[k].detach().cpu().numpy() if torch.is_tensor(got[k]) else np.asarray(got[k])
+        b = want[k].detach().cpu().numpy() if torch.is_tensor(want[k]) else np.asarray(want[k])
+        res[k] = (rel_err(a, b), elem_err(a, b, OUT_FLOOR.get(k)))
+    return res
+
+
+def capture_decisions(out, model, border=5e-7):
+    """Read the piecewise-constant decisions the HIP forward took (ReLU masks of every LayerNorm+ReLU,
+    pool arg-max rows) off the autograd nodes of a PointCloudToWireframe output dict, BEFORE backward.
+
+    Returns (frozen dict for oracle.model_forward(frozen=...), n_border): n_border counts activations
+    whose LayerNorm output lies within `border` of 0 — there the mask recomputed here could differ from
+    the one the kernels take (they evaluate the same fp32 expression in their own order), so a
+    decision-frozen comparison is only meaningful on inputs with n_border == 0."""
+    relu, n_border = {}, 0
+
+    def mask(name, z, mu, rs):
+        nonlocal n_border
+        sd = model.state_dict()
+        g, b = sd[name + ".weight"], sd[name + ".bias"]
+        v = ((z.double() - mu.double()[:, None]) * rs.double()[:, None]) * g.double() + b.double()
+        n_border += int((v.abs() < border).sum())
+        relu[name] = (v > 0).cpu()
+
+    vfn = out["existence_probabilities"].grad_fn
+    ffn = out["global_features"].grad_fn
+    assert type(vfn).__name__.startswith("VertexFn") and type(ffn).__name__.startswith("FusionFn")
+    efn = ffn.next_functions[0][0]
+    assert type(efn).__name__.startswith("EncoderFn")
+    x2, valid, zs, stats, hs, arg_m, arg_u, cnt = efn.saved
+    for i, (z, (mu, rs)) in enumerate(zip(zs, stats)):
+        mask(f"encoder.mlp.{4 * i + 1}", z, mu, rs)
+    pooled, f0, s0, f3, s3 = ffn.saved
+    mask("encoder.feature_fusion.1", f0, *s0)
+    mask("encoder.feature_fusion.4", f3, *s3)
+    pooled_v, e, z1, s1, z2, s2, z3, s3v, c, z4, s4, d = vfn.saved
+    for k, (z, s) in enumerate(((z1, s1), (z2, s2), (z3, s3v), (z4, s4)), start=1):
+        mask(f"vertex_predictor.vertex_mlp{k}.1", z, *s)
+    frozen = {"relu": relu,
+              "argmax": {"enc_masked": arg_m.long().cpu(), "vert_unmasked": arg_u.long().cpu()}}
+    return frozen, n_border
+
+
 def check_grad_summaries(gold, named_grads, tol, skip=()):
     """Compare per-parameter grad (norm, probe-dot, first 64) with a fixture."""
     bad = []

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -90,3 +91,16 @@ def test_same_seed_gives_reference_initialisation():
                        capture_output=True, text=True, timeout=600,
                        env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
     assert "INIT_IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_edge_index_lists_are_read_only_and_equal_to_plain_lists():
+    from wf3d.functional import edge_index_lists
+    a = edge_index_lists([4, 2])
+    assert a[0] == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]] and a[1] == [[0, 1]]
+    assert isinstance(a[0], list) and isinstance(a[0][0], list)
+    assert np.array(a[0]).shape == (6, 2)
+    with pytest.raises(TypeError):
+        a[0].pop()
+    with pytest.raises(TypeError):
+        a[0][0][1] = 9
+    assert edge_index_lists([4])[0] == oracle.edge_index_pairs(4)

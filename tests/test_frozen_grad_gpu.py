@@ -1,0 +1,110 @@
+"""Decision-frozen gradient parity.
+
+A ReLU / arg-max network's gradient is piecewise constant in its pre-activations: two correct
+implementations that sum in a different order may take a different 0/1 decision on an activation that
+is 0 to within an ulp, and then differ by a whole row's contribution in one gradient element.  The
+"with flips" tests (test_model_gpu.py, 1e-3) cannot tell such a flip from a 1e-3 arithmetic error in
+a backward kernel.  This test can: the HIP forward's own decisions (every ReLU mask, both pools'
+arg-max rows) are read off its autograd nodes and imposed on an fp64 run of the CPU oracle
+(oracle.model_forward(frozen=...)), which turns the network into a smooth function evaluated at the
+same point — and then EVERY element of EVERY parameter gradient has to agree:
+
+    |g_hip - g_oracle64| <= 1e-4 * max(|g_oracle64|, rms(g_oracle64))        (north_star: 1e-4 fp32)
+
+Inputs are drawn until no LayerNorm output lies within 5e-7 of 0 (there the mask this test recomputes
+from the saved pre-activations could differ from the kernels' own), so the imposed decisions are
+exactly the ones the kernels took, forward and backward.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import helpers as H  # noqa: E402
+from helpers import oracle  # noqa: E402
+
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _case(seed, B, N, V, counts):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, N, 8, generator=g)
+    x[0, N - N // 4:] = 0.0                       # zero-padded tail in cloud 0 (mask-aware vs unmasked pools differ)
+    cot = None
+    return x, torch.tensor(counts), g, cot
+
+
+def _run(precision, B, N, V, counts):
+    from wf3d import config
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    old = (config.precision(), config.SPLIT_MIN_ROWS)
+    config.set_precision(precision)
+    config.SPLIT_MIN_ROWS = 1
+    try:
+        torch.manual_seed(20)
+        model = PointCloudToWireframe(8, V).to(dev()).set_dropout(0.0)
+        model.train()
+        # give LayerNorm affines and biases non-trivial values (default init is gamma=1, beta=0)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
+        for seed in range(100, 132):
+            x, cnt, gen, _ = _case(seed, B, N, V, counts)
+            model.zero_grad(set_to_none=True)
+            out = model(x.to(dev()), cnt.to(dev()))
+            frozen, n_border = H.capture_decisions(out, model)
+            if n_border == 0:
+                break
+        else:
+            pytest.fail("no borderline-free input found in 32 draws")
+        cot = {k: torch.randn(out[k].shape, generator=gen) for k in ("vertices", "existence_probabilities", "edge_probs")}
+        sum((out[k] * cot[k].to(dev())).sum() for k in cot).backward()
+        got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
+        P = oracle.params_from_module(model, dtype=torch.float64)
+        ref = oracle.model_forward(P, x.double(), cnt, V, training=True, frozen=frozen)
+        sum((ref[k] * cot[k].double()).sum() for k in cot).backward()
+        assert out["edge_indices"] == ref["edge_indices"]
+        fwd = H.out_errs(out, ref)
+        errs = {}
+        for n in P:
+            if P[n].grad is None:
+                assert n not in got, n
+                continue
+            errs[n] = H.elem_err(got[n], P[n].grad.numpy())
+        return fwd, errs, seed
+    finally:
+        config.set_precision(old[0])
+        config.SPLIT_MIN_ROWS = old[1]
+
+
+@pytest.mark.parametrize("B,N,V,counts", [(2, 96, 8, [8, 5]), (3, 160, 12, [12, 2, 7])])
+def test_frozen_gradients_fp32_elementwise(B, N, V, counts):
+    fwd, errs, seed = _run("fp32", B, N, V, counts)
+    worst = sorted(((e, n) for n, e in errs.items()), reverse=True)
+    print(f"fp32 frozen-decision gradients (input seed {seed}): worst element-wise errors", [(f"{e:.1e}", n) for e, n in worst[:5]])
+    print("forward (max-abs rel, element-wise):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in fwd.items()})
+    for k, (a, b) in fwd.items():
+        assert a < TOL and b < TOL, (k, a, b)
+    assert len(errs) == 76                      # all 80 state_dict tensors but the never-used spatial_proj's four
+    bad = [(n, e) for n, e in errs.items() if not e <= TOL]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("B,N,V,counts", [(2, 96, 8, [8, 5])])
+def test_frozen_gradients_bf16x3_measured(B, N, V, counts):
+    """The split-precision mode under the same test.  Its products carry ~2^-17 relative error per
+    operand instead of 2^-24, so element-wise agreement is looser than fp32's; the bound asserted
+    here is the measured one, the forward outputs stay inside 1e-4."""
+    fwd, errs, seed = _run("bf16x3", B, N, V, counts)
+    worst = sorted(((e, n) for n, e in errs.items()), reverse=True)
+    print(f"bf16x3 frozen-decision gradients (input seed {seed}): worst element-wise errors", [(f"{e:.1e}", n) for e, n in worst[:5]])
+    for k, (a, b) in fwd.items():
+        assert a < TOL and b < TOL, (k, a, b)
+    bad = [(n, e) for n, e in errs.items() if not e <= 5e-4]
+    assert not bad, bad

@@ -1,12 +1,16 @@
-"""Size-independent properties of the path, checked at BASELINE.json's full cfg2 size
-(B=32, N=4096, V=64) where the CPU oracle would take minutes:
+"""Size-independent properties of the path, checked at BASELINE.json's FULL single-GPU sizes — cfg2
+(B=32, N=4096, V=64), cfg4 (B=8, N=16384, V=64) and cfg5 (B=32, N=4096, V=256) — where the CPU
+oracle would take minutes to hours:
 
   * permutation invariance over points (PointNet symmetry),
   * batch independence (a sample's outputs do not depend on its batch mates),
   * zero-padded points leave the mask-aware global feature unchanged,
   * backward is linear in the cotangent,
-  * the bf16x3 split-precision mode agrees with the exact-fp32 mode inside the 1e-4 gate,
-  * cfg4 (N=16384) and cfg5 (V=256) shapes run and stay finite.
+  * the bf16x3 split-precision mode agrees with the exact-fp32 mode inside the 1e-4 gate.
+
+Every comparison is held both ways: max-abs error over the tensor's max (`rel`) and element-wise
+(`elem`: each value against max(|its own value|, floor), floor = 1e-6 for probabilities and the
+tensor's rms for signed outputs — helpers.elem_err).
 """
 import pytest
 import torch
@@ -15,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 import helpers as H  # noqa: E402,F401
 
-B, N, V = 32, 4096, 64
 TOL = 1e-4
+CFGS = {"cfg2": (32, 4096, 64), "cfg4": (8, 16384, 64), "cfg5": (32, 4096, 256)}
 
 
 def dev():
@@ -27,17 +31,38 @@ def rel(a, b):
     return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
 
 
-@pytest.fixture(scope="module")
-def setup():
+def elem(a, b, key):
+    """Element-wise relative error on the device (helpers.elem_err semantics)."""
+    a, b = a.double(), b.double()
+    if b.numel() == 0:
+        return 0.0
+    floor = H.OUT_FLOOR.get(key)
+    if floor is None:
+        floor = float(b.square().mean().sqrt())
+    return float(((a - b).abs() / b.abs().clamp_min(max(floor, 1e-300))).max())
+
+
+def close(a, b, key):
+    return rel(a, b) < TOL and elem(a, b, key) < TOL
+
+
+@pytest.fixture(scope="module", params=list(CFGS))
+def setup(request):
     from models.PointCloudToWireframe import PointCloudToWireframe
+    B, N, V = CFGS[request.param]
     torch.manual_seed(1234)
     model = PointCloudToWireframe(8, V).to(dev()).set_dropout(0.0)
     model.train()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, N, 8, generator=g).to(dev())
-    counts = torch.randint(2, V + 1, (B,), generator=g).to(dev())
+    counts = torch.randint(2, V + 1, (B,), generator=g)
+    counts[0] = V                                     # the widest sample is always present
+    counts = counts.to(dev())
     out = model(x, counts)
-    return model, x, counts, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+    assert out["edge_probs"].shape == (B, V * (V - 1) // 2)
+    yield model, x, counts, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+    del model, x, out
+    torch.cuda.empty_cache()
 
 
 KEYS = ("vertices", "existence_probabilities", "edge_probs", "global_features")
@@ -45,28 +70,30 @@ KEYS = ("vertices", "existence_probabilities", "edge_probs", "global_features")
 
 def test_point_permutation_invariance(setup):
     model, x, counts, base = setup
-    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(dev())
+    perm = torch.randperm(x.shape[1], generator=torch.Generator().manual_seed(1)).to(dev())
     out = model(x[:, perm], counts)
     for k in KEYS:
-        assert rel(out[k].detach(), base[k]) < TOL, k
+        assert close(out[k].detach(), base[k], k), (k, rel(out[k].detach(), base[k]), elem(out[k].detach(), base[k], k))
     assert out["edge_indices"] == base["edge_indices"]
 
 
 def test_batch_independence(setup):
     model, x, counts, base = setup
-    for i in (0, 17, 31):
+    B = x.shape[0]
+    for i in (0, B // 2 + 1, B - 1):
         out = model(x[i:i + 1], counts[i:i + 1])
         e = out["edge_probs"].shape[1]
-        assert rel(out["vertices"].detach(), base["vertices"][i:i + 1]) < TOL
-        assert rel(out["edge_probs"].detach(), base["edge_probs"][i:i + 1, :e]) < TOL
+        assert close(out["vertices"].detach(), base["vertices"][i:i + 1], "vertices")
+        assert close(out["existence_probabilities"].detach(), base["existence_probabilities"][i:i + 1], "existence_probabilities")
+        assert close(out["edge_probs"].detach(), base["edge_probs"][i:i + 1, :e], "edge_probs")
         assert float(base["edge_probs"][i, e:].abs().max()) == 0.0 if e < base["edge_probs"].shape[1] else True
 
 
 def test_zero_padding_leaves_masked_global_feature(setup):
     model, x, counts, base = setup
-    xp = torch.cat([x, torch.zeros(B, 512, 8, device=dev())], dim=1)
+    xp = torch.cat([x, torch.zeros(x.shape[0], 512, 8, device=dev())], dim=1)
     g, _pf = model.encoder(xp)
-    assert rel(g.detach(), base["global_features"]) < TOL
+    assert close(g.detach(), base["global_features"], "global_features")
 
 
 def test_backward_is_linear_in_the_cotangent(setup):
@@ -100,11 +127,11 @@ def test_split_precision_agrees_with_fp32_at_full_size(setup):
     finally:
         config.set_precision("bf16x3")
     for k in KEYS:
-        assert rel(base[k], out[k].detach()) < TOL, k
+        assert close(base[k], out[k].detach(), k), (k, rel(base[k], out[k].detach()), elem(base[k], out[k].detach(), k))
 
 
-@pytest.mark.parametrize("b,n,v", [(8, 16384, 64), (4, 4096, 256)])
-def test_other_baseline_shapes_run(b, n, v):
+@pytest.mark.parametrize("b,n,v", [(8, 16384, 64), (32, 4096, 256)])
+def test_baseline_shapes_run_with_dropout_on(b, n, v):
     from models.PointCloudToWireframe import PointCloudToWireframe
     torch.manual_seed(3)
     model = PointCloudToWireframe(8, v).to(dev())

@@ -21,7 +21,7 @@ class PointCloudToWireframe(nn.Module):
         self.encoder = PointNetEncoder(input_dim=input_dim)
         self.vertex_predictor = VertexPredictor(global_feature_dim=512, max_vertices=max_vertices)
         self.edge_predictor = EdgePredictor(vertex_dim=3)
-        self._count_cache = (None, None)
+        self._count_cache = (None, -1, None)         # (the tensor object itself, its _version, host ints)
 
     def set_dropout(self, p):
         """Set every dropout probability of the edge head (the only non-zero ones)."""
@@ -31,16 +31,20 @@ class PointCloudToWireframe(nn.Module):
         return self
 
     def _host_counts(self, t):
-        """Vertex counts as Python ints.  One device->host read (the reference does
-        one `.item()` per sample, :80/:90); the read is skipped when the same
-        unmodified tensor is passed again, as train.py does every step."""
+        """Vertex counts as Python ints.  One device->host read per call (the reference does one
+        `.item()` per sample, :80/:90).  The read is skipped only when the SAME tensor object is
+        passed again unmodified, as train.py does every step (train.py:127): the cache holds a
+        reference to that tensor — so its storage cannot be freed and handed to another batch's
+        counts — and compares identity plus the autograd version counter, which every in-place
+        torch op bumps.  (Writes that bypass the counter — `.data`, raw pointers — are not seen;
+        pass a CPU tensor or a fresh tensor then.)  CPU tensors are read directly, no sync."""
         if not t.is_cuda:
             return [int(c) for c in t.tolist()]
-        key = (t.data_ptr(), t._version, t.numel())
-        if self._count_cache[0] == key:
-            return self._count_cache[1]
+        ref, ver, vals = self._count_cache
+        if ref is t and ver == t._version:
+            return vals
         vals = [int(c) for c in t.tolist()]
-        self._count_cache = (key, vals)
+        self._count_cache = (t, t._version, vals)
         return vals
 
     def forward(self, point_cloud, target_vertex_counts=None):

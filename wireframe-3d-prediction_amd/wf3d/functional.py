@@ -18,6 +18,16 @@ from . import config, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, NN, NT, TN, Pro
 
 
+def _saved(ctx):
+    """The activations a stage kept for its backward.  They are released by the first backward (2.7 GB
+    at cfg2), so a second one through the same graph (retain_graph=True) cannot be served: say so
+    instead of failing on a None unpack."""
+    if ctx.saved is None:
+        raise RuntimeError("wf3d: backward through this graph a second time — the stage's saved activations were "
+                           "released by the first backward (retain_graph is not supported); re-run the forward")
+    return ctx.saved
+
+
 def _lin_bwd(dz, a, W, pro_a, need_da=True):
     """Linear backward pieces for z = pro(a)·W^T + b given dz:
     dW = dz^T·pro(a) (TN, prologue re-applied to the stored pre-activation),
@@ -120,7 +130,7 @@ class EncoderFn(torch.autograd.Function):
         nh, (B, N, C), split = ctx.n_hidden, ctx.dims, ctx.split
         M = B * N
         params = ctx.params
-        x2, valid, zs, stats, hs, arg_m, arg_u, cnt = ctx.saved
+        x2, valid, zs, stats, hs, arg_m, arg_u, cnt = _saved(ctx)
         grads = [None] * len(params)
         dmmax = dpooled[:, :C].contiguous() if dpooled is not None else None
         dmavg = dpooled[:, C:].contiguous() if dpooled is not None else None
@@ -209,7 +219,7 @@ class FusionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dgl):
         F = ctx.params
-        pooled, f0, s0, f3, s3 = ctx.saved
+        pooled, f0, s0, f3, s3 = _saved(ctx)
         G = [None] * 10
         dgl = dgl.contiguous()
         G[9] = ops.colsum(dgl)
@@ -263,7 +273,7 @@ class VertexFn(torch.autograd.Function):
         params = ctx.params
         B, V, vd = ctx.dims
         (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4, g4, be4, Wf, bf, Wr1, br1, Wr2, br2) = params[:22]
-        pooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d = ctx.saved
+        pooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d = _saved(ctx)
         (exist,) = ctx.saved_tensors
         G = [None] * len(params)
         do = ops.vertex_finalize_bwd(exist, dexist.contiguous() if dexist is not None else None,
@@ -364,7 +374,7 @@ class EdgeFn(torch.autograd.Function):
         (P0w, P0b, P1g, P1b, P3w, P3b, P4g, P4b, Aw, Ab, Ow, Ob,
          M0w, M0b, M1g, M1b, M4w, M4b, M5g, M5b, M8w, M8b, M10w, M10b) = params
         B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta = ctx.cfg
-        cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2 = ctx.saved
+        cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2 = _saved(ctx)
         (probs,) = ctx.saved_tensors
         G = [None] * len(params)
         dlogit = ops.edge_prob_bwd(probs, dprobs.contiguous(), meta)                      # [Re,1]
@@ -452,16 +462,38 @@ class EdgeFn(torch.autograd.Function):
         return (dverts, None, None, None, None, None, *G)
 
 
-def edge_index_lists(counts, _cache={}):
+class _FrozenList(list):
+    """A list that refuses in-place mutation.  edge_index_lists hands the SAME cached object to every
+    sample and every forward with that vertex count (the reference builds fresh lists each call,
+    EdgePredictor.py:88-89,140 — 63 ms per sample at V=256); a caller that filtered one in place would
+    corrupt every later forward, so mutation raises instead.  Compares equal to / converts like a list."""
+    __slots__ = ()
+
+    def _ro(self, *a, **k):
+        raise TypeError("edge_indices lists are shared between calls and read-only: copy first "
+                        "(e.g. [list(p) for p in out['edge_indices'][i]])")
+
+    append = extend = insert = remove = pop = clear = sort = reverse = _ro
+    __setitem__ = __delitem__ = __iadd__ = __imul__ = _ro
+
+
+_EDGE_LIST_CACHE = {}          # vertex count -> _FrozenList of _FrozenList([i, j]); LRU, bounded
+_EDGE_LIST_CACHE_MAX = 128     # 2.6 MB of host memory per entry at V=256
+
+
+def edge_index_lists(counts):
     """Per-sample list of [i, j] pairs, i < j, lexicographic — bit-identical to
     EdgePredictor._get_edge_indices(...).tolist() (reference :70-89,140), but
-    built once per vertex count and cached instead of re-looped on every call."""
+    built once per vertex count and cached (LRU) instead of re-looped on every call."""
     out = []
     for c in counts:
-        lst = _cache.get(c)
+        lst = _EDGE_LIST_CACHE.pop(c, None)
         if lst is None:
-            lst = _cache[c] = [[i, j] for i in range(c) for j in range(i + 1, c)]
-        out.append(lst)          # shared, read-only by convention (callers only index it)
+            lst = _FrozenList(_FrozenList((i, j)) for i in range(c) for j in range(i + 1, c))
+            if len(_EDGE_LIST_CACHE) >= _EDGE_LIST_CACHE_MAX:
+                _EDGE_LIST_CACHE.pop(next(iter(_EDGE_LIST_CACHE)))
+        _EDGE_LIST_CACHE[c] = lst          # (re-)insert as most recently used
+        out.append(lst)
     return out
 
 
@@ -481,7 +513,7 @@ class UnmaskedPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dumean, dumax):
         B, N, C = ctx.dims
-        ones, cnt, arg_m, arg_u = ctx.saved
+        ones, cnt, arg_m, arg_u = _saved(ctx)
         dumean = dumean.contiguous() if dumean is not None else None
         dumax = dumax.contiguous() if dumax is not None else None
         return ops.pool4_bwd(ones, cnt, arg_m, arg_u, None, None, dumean, dumax, None, B, N, C)
