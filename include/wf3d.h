@@ -188,6 +188,72 @@ int wf3d_rowdot_act_bwd(const float* z, const float* dlogit, int R, int D, const
                         void* dz_sx8, float* dw, float* dbias_z, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * "Skinny" Linear layers: M <= 32 rows (one per cloud of the batch) — the feature-fusion MLP
+ * (models/PointNetEncoder.py:57-65,116) and the vertex head (models/VertexPredictor.py:94-117),
+ * forward and backward.  Replaces, per nn.Linear: aten::addmm, the native_layer_norm / relu_ in
+ * front of it and the residual add behind it; in backward the two mm's, native_layer_norm_backward,
+ * threshold_backward and the bias sum.  Pure weight streaming (csrc/skinny.hip): LayerNorm
+ * statistics travel as per-16-column (mean, M2) partials from the producing launch to the
+ * consuming one, the LayerNorm backward's row sums as per-64-column partials, so neither pass
+ * exists as a kernel.  Up to WF3D_SKINNY_MAX_PROBLEMS Linears per launch.
+ * ------------------------------------------------------------------------ */
+#define WF3D_SKINNY_MAX_ROWS 32
+#define WF3D_SKINNY_MAX_PROBLEMS 4
+
+/* Y[M,N] = x'·W^T + bias + out_addend,  x' = act(LayerNorm(X; gamma, beta)) + in_addend  (gamma NULL: x' = X + in_addend).
+ * LayerNorm statistics of X: merged from in_part [in_nblk = K/16][M][2] (what the launch that wrote X left in its
+ * stat_part) and, when mu_out != NULL, stored to mu_out/rs_out [M] for backward; or given as mu/rs [M]. */
+typedef struct wf3d_skinny_fwd_t {
+    const float* X; int ldx;
+    const float* W; int ldw;            /* [N, K] (nn.Linear weight) */
+    const float* bias;                  /* [N] or NULL */
+    float* Y; int ldy;
+    int N, K;
+    const float* gamma; const float* beta; int act;      /* input prologue (WF3D_ACT_*) */
+    const float* in_part; int in_nblk;  /* statistics partials of X, or NULL */
+    const float* mu; const float* rs;   /* ... or final statistics */
+    float* mu_out; float* rs_out;       /* [M] or NULL */
+    const float* in_addend; int ld_in_addend;
+    const float* out_addend; int ld_out_addend;
+    float* stat_part;                   /* [N/16][M][2] (mean, M2) of Y per 16-column block, or NULL (needs N % 16 == 0) */
+} wf3d_skinny_fwd_t;
+int wf3d_skinny_ok(int M, int K);
+int wf3d_skinny_fwd(const wf3d_skinny_fwd_t* probs, int nprob, int M, float eps, void* stream);
+
+/* Backward of one Linear y = x'·W^T + b given the gradient of its output:
+ *   plain form (z == NULL):  dz = dY
+ *   LayerNorm form:          dY holds G = dh * act'(LN(z)) * gamma (wf3d_skinny_reduce), z/mu/rs this Linear's own
+ *                            pre-LayerNorm output and statistics, rowpart [rowpart_nblk][M][2] the partial row sums of
+ *                            (G, G*xhat):  dz = rs * (G - mean(G) - xhat * mean(G*xhat))
+ * Outputs: dW[N,K] = dz^T·x' and db[N] = colsum(dz) (x' rebuilt from X with the forward's prologue; dW NULL skips
+ * both), and slabs [ceil(N/nc)][M][K]: partial dgrad dX_s = dz[:, s*nc:(s+1)*nc]·W[s*nc:(s+1)*nc, :] (NULL skips). */
+typedef struct wf3d_skinny_bwd_t {
+    const float* dY; int lddy;
+    const float* z; int ldz; const float* mu; const float* rs; const float* rowpart; int rowpart_nblk;
+    const float* W; int ldw; int N, K;
+    const float* X; int ldx;
+    const float* xmu; const float* xrs; const float* xgamma; const float* xbeta; int xact;
+    const float* xadd; int ldxadd;
+    float* dW; int lddw; float* db;
+    float* slabs; int nc;
+} wf3d_skinny_bwd_t;
+size_t wf3d_skinny_slab_floats(int M, int N, int K, int nc);
+int wf3d_skinny_bwd(const wf3d_skinny_bwd_t* probs, int nprob, int M, void* stream);
+
+/* v[M,K] = sum of up to three slab sets (fixed order: deterministic) + extra; optionally stored to dh.  With z != NULL
+ * v is the gradient of h = act(LayerNorm(z)) and the elementwise half of that backward is applied in the same pass:
+ * G = v*act'*gamma -> G[M,K], dgamma[K], dbeta[K], rowpart [ceil(K/64)][M][2] = per-block row sums of (G, G*xhat). */
+typedef struct wf3d_skinny_red_t {
+    const float* slabs[3]; int nslab[3];
+    const float* extra; int ldextra;
+    int K;
+    float* dh; int lddh;
+    const float* z; int ldz; const float* mu; const float* rs; const float* gamma; const float* beta; int act;
+    float* G; int ldg; float* dgamma; float* dbeta; float* rowpart;
+} wf3d_skinny_red_t;
+int wf3d_skinny_reduce(const wf3d_skinny_red_t* prob, int M, void* stream);
+
+/* ------------------------------------------------------------------------
  * Pools (PointNetEncoder.py:85-86,103-111 and VertexPredictor.py:86-88)
  * ------------------------------------------------------------------------ */
 /* valid[m] = (sum_k |x[m,k]| > 1e-9) ? 1 : 0 */
@@ -198,17 +264,26 @@ int wf3d_point_valid(const float* x, int M, int in_dim, float* valid, void* stre
  * index, masked mean over max(count,1), unmasked mean, unmasked max + index,
  * and cnt[b] = max(#valid, 1). */
 size_t wf3d_pool4_ws_bytes(int B, int N, int C);
+/* The four pooled [B, C] outputs are written with row stride ldo (>= C), so that [max | avg] and [mean | max] can be
+ * the two halves of the [B, 2C] vectors the fusion MLP / the vertex head consume (the reference's torch.cat,
+ * PointNetEncoder.py:115, VertexPredictor.py:88); nvalid[b] (optional) = the unclamped number of valid points. */
 int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N, int C, float* mmax, float* mavg,
-                   float* umean, float* umax, int32_t* arg_m, int32_t* arg_u, float* cnt, void* ws,
-                   size_t ws_bytes, void* stream);
-/* dpf[b,n,c] = valid*dmavg/cnt + dumean/N + [n==arg_m]*dmmax + [n==arg_u]*dumax (+ dpf_direct) */
+                   float* umean, float* umax, int ldo, int32_t* arg_m, int32_t* arg_u, float* cnt, float* nvalid,
+                   void* ws, size_t ws_bytes, void* stream);
+/* dpf[b,n,c] = valid*dmavg/cnt + dumean/N + [n==arg_m]*dmmax + [n==arg_u]*dumax (+ dpf_direct);
+ * the masked / unmasked cotangent pairs have row strides ldm / ldu (halves of [B, 2C] gradients). */
 int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
-                   const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                   const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax, int ldu,
                    const float* dpf_direct, int B, int N, int C, float* dpf, void* stream);
+/* dbias[c] = sum over all B*N rows of the dpf above without dpf_direct — the bias gradient of the Linear that
+ * produced point_features (encoder.mlp.16) — from the [B, C] cotangents alone. */
+int wf3d_pool4_bwd_bias(const float* cnt, const float* nvalid, const int32_t* arg_m, const int32_t* arg_u,
+                        const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax, int ldu,
+                        int B, int C, float* dbias, void* stream);
 /* Same values written as the sx8 split operand of the output Linear's dgrad / wgrad GEMMs (C % 8 == 0):
  * saves the fp32 round trip through wf3d_split_rows. */
 int wf3d_pool4_bwd_sx8(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
-                       const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                       const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax, int ldu,
                        const float* dpf_direct, int B, int N, int C, float* dpf_sx8, void* stream);
 
 /* ------------------------------------------------------------------------

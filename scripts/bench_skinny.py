@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-launch time of the skinny (M = batch rows) kernels at the fusion-MLP / vertex-head shapes of cfg2 (csrc/skinny.hip),
+beside the bytes each launch has to move.  `python scripts/bench_skinny.py [M]`"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wireframe-3d-prediction_amd"))
+import torch  # noqa: E402
+
+from wf3d import skinny as sk  # noqa: E402
+
+dev = torch.device("cuda:0")
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+R = 1
+
+
+def t(fn, iters=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def rnd(*s):
+    return torch.randn(*s, device=dev)
+
+
+flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+print(f"M = {M}")
+for name, N, K in [("fusion.0", 2048, 1024), ("fusion.3", 1024, 2048), ("fusion.6", 512, 1024), ("vertex_mlp1", 4096, 512),
+                   ("vertex_mlp2", 2048, 4096), ("vertex_mlp3", 2048, 2048), ("vertex_mlp4", 1024, 2048), ("final", 256, 1024)]:
+    X, W, b = rnd(M, K), rnd(N, K) * K ** -0.5, rnd(N)
+    g, be = rnd(K), rnd(K)
+    (Xp, part, _), = sk.fwd(M, sk.Fwd(rnd(M, 64), rnd(K, 64), None, stats=True)) if K % 16 == 0 else (None, None, None)
+    t_plain = t(lambda: sk.fwd(M, sk.Fwd(X, W, b, stats=N % 16 == 0)))
+    t_ln = t(lambda: sk.fwd(M, sk.Fwd(Xp, W, b, ln=sk.LNIn(g, be, R, part=part), stats=N % 16 == 0)))
+    dY = rnd(M, N)
+    t_bwd = t(lambda: sk.bwd(M, sk.Bwd(dY, W, X)))
+    (_, _, sl), = sk.bwd(M, sk.Bwd(dY, W, X))
+    z, mu, rs = rnd(M, K), rnd(M), rnd(M).abs() + 0.5
+    t_red = t(lambda: sk.reduce(M, K, [sl], ln=(z, mu, rs, g, be, R)))
+    mb = N * K * 4 / 1e6
+    print(f"{name:12s} N={N:5d} K={K:5d} W={mb:6.1f} MB | fwd {t_plain:6.1f} us  fwd+LN {t_ln:6.1f} us ({mb / t_ln * 1e3 / 1e3:5.2f} TB/s)"
+          f" | bwd {t_bwd:6.1f} us ({2 * mb / t_bwd:5.2f} TB/s) | reduce[{sl.shape[0]} slabs] {t_red:6.1f} us")

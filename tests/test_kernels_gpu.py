@@ -220,7 +220,11 @@ def test_pool4_fwd_bwd(ops, B, N, C):
     valid = ops.point_valid(x)
     vm = x.abs().sum(-1) > 1e-9
     assert torch.equal(valid.reshape(B, N) > 0, vm)
-    mmax, mavg, umean, umax, arg_m, arg_u, cnt = ops.pool4_fwd(pf, valid)
+    po = ops.pool4_fwd(pf, valid, packed=True)
+    mmax, mavg, umean, umax, arg_m, arg_u, cnt = po.mmax, po.mavg, po.umean, po.umax, po.arg_m, po.arg_u, po.cnt
+    # the packed [B, 2C] vectors are the reference's torch.cat orders (PointNetEncoder.py:115, VertexPredictor.py:88)
+    assert torch.equal(po.masked, torch.cat([mmax, mavg], 1)) and torch.equal(po.unmasked, torch.cat([umean, umax], 1))
+    assert torch.equal(po.nvalid.cpu(), vm.sum(1).float().cpu())
     # reference formulation (oracle.encoder_pools / VertexPredictor pools)
     from helpers import oracle
     pfc = pf.cpu().requires_grad_()
@@ -240,8 +244,14 @@ def test_pool4_fwd_bwd(ops, B, N, C):
     assert rel(dpf2, pfc.grad + direct.cpu()) < TOL_ELT
     # column sums from the [B, C] cotangents alone == column sums of the scattered tensor
     for d, full in ((None, dpf), (direct, dpf2)):
-        cs = ops.pool4_bwd_colsum(valid, cnt, arg_m, arg_u, cot[0], cot[1], cot[2], cot[3], d, B, N, C)
+        cs = ops.pool4_bwd_colsum(po.nvalid, cnt, arg_m, arg_u, cot[0], cot[1], cot[2], cot[3], d, B, N, C)
         assert rel(cs, full.double().sum((0, 1))) < 2e-5
+    # cotangents as the two halves of [B, 2C] gradients (what the fusion MLP / vertex head hand back)
+    gm, gu = torch.cat([cot[0], cot[1]], 1), torch.cat([cot[2], cot[3]], 1)
+    dpf3 = ops.pool4_bwd(valid, cnt, arg_m, arg_u, gm[:, :C], gm[:, C:], gu[:, :C], gu[:, C:], None, B, N, C)
+    assert torch.equal(dpf3, dpf)
+    cs3 = ops.pool4_bwd_colsum(po.nvalid, cnt, arg_m, arg_u, gm[:, :C], gm[:, C:], gu[:, :C], gu[:, C:], None, B, N, C)
+    assert rel(cs3, dpf.double().sum((0, 1))) < 2e-5
     if C % 8 == 0:
         # sx8 output: hi + lo planes reproduce the fp32 result to the split format's 2^-17
         for d, full in ((None, dpf), (direct, dpf2)):

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void pool4_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __restrict__ part,
                                                            const float* __restrict__ cnt_part, int N, int C,
-                                                           int nsplit, float* __restrict__ mmax_o,
+                                                           int nsplit, int ldo, float* __restrict__ nvalid_o,
+                                                           float* __restrict__ mmax_o,
                                                            float* __restrict__ mavg_o, float* __restrict__ umean_o,
                                                            float* __restrict__ umax_o, int32_t* __restrict__ arg_m_o,
                                                            int32_t* __restrict__ arg_u_o, float* __restrict__ cnt_o) {
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __rest
     float cnt = 0.f;
     for (int s = 0; s < nsplit; ++s) cnt += cnt_part[b * nsplit + s];
     const float cl = fmaxf(cnt, 1.0f);                      // clamp(min=1), PointNetEncoder.py:86
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt_o[b] = cl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt_o[b] = cl;
+        if (nvalid_o) nvalid_o[b] = cnt;
+    }
     if (c >= C) return;
     float msum = 0.f, usum = 0.f, mmax = -INFINITY, umax = -INFINITY;
     int am = -1, au = -1;
@@ -73,14 +77,14 @@ __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __rest
         if (q.arg_u >= 0 && (q.umax > umax || au < 0)) { umax = q.umax; au = q.arg_u; }
         if (q.arg_m >= 0 && (q.mmax > mmax || am < 0)) { mmax = q.mmax; am = q.arg_m; }
     }
-    const size_t o = (size_t)b * C + c;
+    const size_t o = (size_t)b * C + c, ov = (size_t)b * ldo + c;
     // where(isfinite(max), max, 0): a cloud with no valid point pools to 0 and passes no gradient
     const bool fin = am >= 0 && isfinite(mmax);
-    mmax_o[o] = fin ? mmax : 0.f;
+    mmax_o[ov] = fin ? mmax : 0.f;
     arg_m_o[o] = fin ? am : -1;
-    mavg_o[o] = msum / cl;
-    umean_o[o] = usum / (float)N;
-    umax_o[o] = umax;
+    mavg_o[ov] = msum / cl;
+    umean_o[ov] = usum / (float)N;
+    umax_o[ov] = umax;
     arg_u_o[o] = au;
 }
 
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict_
                                                          const float* __restrict__ dmmax, const float* __restrict__ dmavg,
                                                          const float* __restrict__ dumean, const float* __restrict__ dumax,
                                                          const float* __restrict__ dpf_direct, int N, int C,
-                                                         int npb, float* __restrict__ dpf) {
+                                                         int npb, int ldm, int ldu, float* __restrict__ dpf) {
     const int b = blockIdx.z;
     const int tpr = C / 4 < 256 ? C / 4 : 256;             // threads per point row
     const int rpb = 256 / tpr;                             // point rows per pass
@@ -104,13 +108,13 @@ __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict_
     const int c = (blockIdx.x * tpr + threadIdx.x % tpr) * 4;
     if (c >= C || rsub >= rpb) return;
     const int n0 = blockIdx.y * npb, n1 = min(N, n0 + npb);
-    const size_t o = (size_t)b * C + c;
+    const size_t o = (size_t)b * C + c, om = (size_t)b * ldm + c, ou = (size_t)b * ldu + c;
     const float inv_cnt = 1.0f / cnt[b], inv_n = 1.0f / (float)N;
     f32x4 g_avg = {0.f, 0.f, 0.f, 0.f}, g_mean = g_avg, g_mm = g_avg, g_um = g_avg;
-    if (dmavg) g_avg = *reinterpret_cast<const f32x4*>(dmavg + o) * inv_cnt;
-    if (dumean) g_mean = *reinterpret_cast<const f32x4*>(dumean + o) * inv_n;
-    if (dmmax) g_mm = *reinterpret_cast<const f32x4*>(dmmax + o);
-    if (dumax) g_um = *reinterpret_cast<const f32x4*>(dumax + o);
+    if (dmavg) g_avg = *reinterpret_cast<const f32x4*>(dmavg + om) * inv_cnt;
+    if (dumean) g_mean = *reinterpret_cast<const f32x4*>(dumean + ou) * inv_n;
+    if (dmmax) g_mm = *reinterpret_cast<const f32x4*>(dmmax + om);
+    if (dumax) g_um = *reinterpret_cast<const f32x4*>(dumax + ou);
     int am[4], au[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { am[j] = arg_m[o + j]; au[j] = arg_u[o + j]; }
@@ -146,16 +150,16 @@ __global__ __launch_bounds__(256) void pool4_bwd_scalar_kernel(const float* __re
                                                                 const float* __restrict__ dmmax, const float* __restrict__ dmavg,
                                                                 const float* __restrict__ dumean, const float* __restrict__ dumax,
                                                                 const float* __restrict__ dpf_direct, int N, int C,
-                                                                int npb, float* __restrict__ dpf) {
+                                                                int npb, int ldm, int ldu, float* __restrict__ dpf) {
     const int b = blockIdx.z;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int n0 = blockIdx.y * npb, n1 = min(N, n0 + npb);
-    const size_t o = (size_t)b * C + c;
-    const float g_avg = dmavg ? dmavg[o] / cnt[b] : 0.f;
-    const float g_mean = dumean ? dumean[o] / (float)N : 0.f;
-    const float g_mm = dmmax ? dmmax[o] : 0.f;
-    const float g_um = dumax ? dumax[o] : 0.f;
+    const size_t o = (size_t)b * C + c, om = (size_t)b * ldm + c, ou = (size_t)b * ldu + c;
+    const float g_avg = dmavg ? dmavg[om] / cnt[b] : 0.f;
+    const float g_mean = dumean ? dumean[ou] / (float)N : 0.f;
+    const float g_mm = dmmax ? dmmax[om] : 0.f;
+    const float g_um = dumax ? dumax[ou] : 0.f;
     const int am = arg_m[o], au = arg_u[o];
     for (int n = n0; n < n1; ++n) {
         const size_t idx = ((size_t)b * N + n) * C + c;
@@ -164,6 +168,38 @@ __global__ __launch_bounds__(256) void pool4_bwd_scalar_kernel(const float* __re
         if (n == au) g += g_um;
         if (dpf_direct) g += dpf_direct[idx];
         dpf[idx] = g;
+    }
+}
+
+// Column sums over all B*N rows of what pool4_bwd writes, from the [B, C] cotangents alone (the bias gradient of the
+// Linear in front of the pool):  sum_b  dmavg*nvalid/cnt + dumean + [arg_m >= 0]*dmmax + [arg_u >= 0]*dumax.
+__global__ __launch_bounds__(256) void pool4_bwd_bias_kernel(const float* __restrict__ cnt, const float* __restrict__ nvalid,
+                                                              const int32_t* __restrict__ arg_m, const int32_t* __restrict__ arg_u,
+                                                              const float* __restrict__ dmmax, const float* __restrict__ dmavg,
+                                                              const float* __restrict__ dumean, const float* __restrict__ dumax,
+                                                              int B, int C, int ldm, int ldu, float* __restrict__ out) {
+    // 32 columns x 8 cloud lanes per workgroup (the clouds' loads are independent), folded in LDS in lane order
+    __shared__ float s_p[8][32];
+    const int cl = threadIdx.x & 31, bg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float acc = 0.f;
+    if (c < C)
+        for (int b = bg; b < B; b += 8) {
+            const size_t o = (size_t)b * C + c, om = (size_t)b * ldm + c, ou = (size_t)b * ldu + c;
+            float v = 0.f;
+            if (dmavg) v += dmavg[om] * (nvalid[b] / cnt[b]);
+            if (dumean) v += dumean[ou];
+            if (dmmax && arg_m[o] >= 0) v += dmmax[om];
+            if (dumax && arg_u[o] >= 0) v += dumax[ou];
+            acc += v;
+        }
+    s_p[bg][cl] = acc;
+    __syncthreads();
+    if (bg == 0 && c < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) a += s_p[g][cl];
+        out[c] = a;
     }
 }
 
@@ -196,8 +232,9 @@ extern "C" size_t wf3d_pool4_ws_bytes(int B, int N, int C) {
 }
 
 extern "C" int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N, int C, float* mmax, float* mavg,
-                              float* umean, float* umax, int32_t* arg_m, int32_t* arg_u, float* cnt, void* ws,
-                              size_t ws_bytes, void* stream) {
+                              float* umean, float* umax, int ldo, int32_t* arg_m, int32_t* arg_u, float* cnt,
+                              float* nvalid, void* ws, size_t ws_bytes, void* stream) {
+    WF3D_CHECK(ldo >= C, WF3D_ERR_ARG, "wf3d_pool4_fwd: ldo=%d < C=%d", ldo, C);
     WF3D_CHECK(B > 0 && N > 0 && C > 0, WF3D_ERR_ARG, "wf3d_pool4_fwd: bad dims B=%d N=%d C=%d", B, N, C);
     WF3D_CHECK(B <= 65535, WF3D_ERR_UNSUPPORTED, "wf3d_pool4_fwd: B > 65535");
     WF3D_CHECK(pf && valid && mmax && mavg && umean && umax && arg_m && arg_u && cnt, WF3D_ERR_ARG, "wf3d_pool4_fwd: null pointer");
@@ -210,34 +247,46 @@ extern "C" int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pool4_partial_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, st, pf, valid, N, C, ns, npb, part, cnt_part);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pool4_final_kernel, dim3(wf3d_cdiv(C, 256), B), dim3(256), 0, st, part, cnt_part, N, C, ns, mmax,
-                       mavg, umean, umax, arg_m, arg_u, cnt);
+    hipLaunchKernelGGL(pool4_final_kernel, dim3(wf3d_cdiv(C, 256), B), dim3(256), 0, st, part, cnt_part, N, C, ns, ldo, nvalid,
+                       mmax, mavg, umean, umax, arg_m, arg_u, cnt);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
 
 static int pool4_bwd_impl(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
-                          const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                          const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax, int ldu,
                           const float* dpf_direct, int B, int N, int C, float* dpf, bool sx8, void* stream);
 
 extern "C" int wf3d_pool4_bwd(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
-                              const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
-                              const float* dpf_direct, int B, int N, int C, float* dpf, void* stream) {
-    return pool4_bwd_impl(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C, dpf, false, stream);
+                              const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax,
+                              int ldu, const float* dpf_direct, int B, int N, int C, float* dpf, void* stream) {
+    return pool4_bwd_impl(valid, cnt, arg_m, arg_u, dmmax, dmavg, ldm, dumean, dumax, ldu, dpf_direct, B, N, C, dpf, false, stream);
 }
 
 extern "C" int wf3d_pool4_bwd_sx8(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
-                                  const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
-                                  const float* dpf_direct, int B, int N, int C, float* dpf_sx8, void* stream) {
-    return pool4_bwd_impl(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C, dpf_sx8, true, stream);
+                                  const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax,
+                                  int ldu, const float* dpf_direct, int B, int N, int C, float* dpf_sx8, void* stream) {
+    return pool4_bwd_impl(valid, cnt, arg_m, arg_u, dmmax, dmavg, ldm, dumean, dumax, ldu, dpf_direct, B, N, C, dpf_sx8, true, stream);
+}
+
+extern "C" int wf3d_pool4_bwd_bias(const float* cnt, const float* nvalid, const int32_t* arg_m, const int32_t* arg_u,
+                                   const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax,
+                                   int ldu, int B, int C, float* dbias, void* stream) {
+    WF3D_CHECK(B > 0 && C > 0 && cnt && nvalid && arg_m && arg_u && dbias, WF3D_ERR_ARG, "wf3d_pool4_bwd_bias: bad arguments");
+    hipLaunchKernelGGL(pool4_bwd_bias_kernel, dim3(wf3d_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, cnt, nvalid, arg_m,
+                       arg_u, dmmax, dmavg, dumean, dumax, B, C, ldm, ldu, dbias);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
 }
 
 static int pool4_bwd_impl(const float* valid, const float* cnt, const int32_t* arg_m, const int32_t* arg_u,
-                          const float* dmmax, const float* dmavg, const float* dumean, const float* dumax,
+                          const float* dmmax, const float* dmavg, int ldm, const float* dumean, const float* dumax, int ldu,
                           const float* dpf_direct, int B, int N, int C, float* dpf, bool sx8, void* stream) {
     WF3D_CHECK(B > 0 && N > 0 && C > 0 && B <= 65535, WF3D_ERR_ARG, "wf3d_pool4_bwd: bad dims");
     WF3D_CHECK(valid && cnt && arg_m && arg_u && dpf, WF3D_ERR_ARG, "wf3d_pool4_bwd: null pointer");
+    const auto al = [](const float* p, int ld) { return !p || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
     const bool vec = C % 4 == 0 && ((uintptr_t)dpf % 16 == 0) && (!dpf_direct || (uintptr_t)dpf_direct % 16 == 0) &&
+                     al(dmmax, ldm) && al(dmavg, ldm) && al(dumean, ldu) && al(dumax, ldu) &&
                      (C / 4 >= 256 || 256 % (C / 4) == 0);
     WF3D_CHECK(!sx8 || (vec && C % 8 == 0), WF3D_ERR_UNSUPPORTED, "wf3d_pool4_bwd_sx8: needs C %% 8 == 0 and 16-B aligned tensors (C=%d)", C);
     if (vec) {
@@ -246,14 +295,14 @@ static int pool4_bwd_impl(const float* valid, const float* cnt, const int32_t* a
         ns = ns > cap ? cap : (ns < 1 ? 1 : ns);
         const int npb = wf3d_cdiv(N, ns);
         if (sx8) hipLaunchKernelGGL(pool4_bwd_kernel<true>, dim3(wf3d_cdiv(C / 4, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
-                                    valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+                                    valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, ldm, ldu, dpf);
         else     hipLaunchKernelGGL(pool4_bwd_kernel<false>, dim3(wf3d_cdiv(C / 4, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
-                                    valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+                                    valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, ldm, ldu, dpf);
     } else {
         const int ns = pool_nsplit(B, N, C);
         const int npb = wf3d_cdiv(N, ns);
         hipLaunchKernelGGL(pool4_bwd_scalar_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, (hipStream_t)stream,
-                           valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, dpf);
+                           valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, N, C, npb, ldm, ldu, dpf);
     }
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;

@@ -48,8 +48,8 @@ class PointCloudToWireframe(nn.Module):
         return vals
 
     def forward(self, point_cloud, target_vertex_counts=None):
-        g, _pf, pooled_mean, pooled_max = self.encoder.encode(point_cloud)
-        vo = self.vertex_predictor.predict(g, pooled_mean, pooled_max)
+        g, _pf, upooled = self.encoder.encode(point_cloud)
+        vo = self.vertex_predictor.predict(g, upooled)
         verts = vo["vertices"]
         if self.training and target_vertex_counts is not None:
             counts = self._host_counts(target_vertex_counts)          # ground-truth counts (:77-86)

@@ -50,15 +50,15 @@ class PointNetEncoder(nn.Module):
                 ff[6].weight, ff[6].bias]
 
     def encode(self, x):
-        """(global, point_features, unmasked_mean, unmasked_max): the two extra
-        pools are what VertexPredictor would recompute from point_features."""
+        """(global, point_features, unmasked_pooled [B, 2C] = [mean | max]): the extra pools are what
+        VertexPredictor would recompute from point_features (VertexPredictor.py:86-88)."""
         if x.dim() != 3:
             raise ValueError(f"expected (batch, num_points, input_dim), got {tuple(x.shape)}")
-        pooled, pf, umean, umax = EncoderFn.apply(x.float(), self._n_hidden, self.precision or config.precision(),
-                                                  *self._mlp_params())
+        pooled, pf, upooled = EncoderFn.apply(x.float(), self._n_hidden, self.precision or config.precision(),
+                                              *self._mlp_params())
         g = FusionFn.apply(pooled, *self._fusion_params())
-        return g, pf, umean, umax
+        return g, pf, upooled
 
     def forward(self, x):
-        g, pf, _, _ = self.encode(x)
+        g, pf, _ = self.encode(x)
         return g, pf

@@ -43,12 +43,12 @@ class VertexPredictor(nn.Module):
             ps += [self.point_pool_proj.weight, self.point_pool_proj.bias]
         return ps
 
-    def predict(self, global_features, pooled_mean, pooled_max):
-        """Vertex head from already-pooled point features (None, None -> no fusion)."""
-        with_pool = pooled_mean is not None
+    def predict(self, global_features, upooled):
+        """Vertex head from already-pooled point features, upooled = [mean | max] [B, 2C] (None -> no fusion)."""
+        with_pool = upooled is not None
         if with_pool:
-            self.ensure_point_pool_proj(2 * pooled_mean.shape[1], pooled_mean.device)
-        o, exist, counts = VertexFn.apply(global_features, pooled_mean, pooled_max, self.max_vertices,
+            self.ensure_point_pool_proj(upooled.shape[1], upooled.device)
+        o, exist, counts = VertexFn.apply(global_features, upooled, self.max_vertices,
                                           self.vertex_dim, *self._param_list(with_pool))
         return {"vertices": o[:, :, :3],                 # non-contiguous view, like the reference (:122)
                 "existence_probabilities": exist,
@@ -56,6 +56,5 @@ class VertexPredictor(nn.Module):
 
     def forward(self, global_features, point_features, target_vertex_counts=None):
         if point_features is not None:
-            mean, mx = UnmaskedPoolFn.apply(point_features.float())
-            return self.predict(global_features, mean, mx)
-        return self.predict(global_features, None, None)
+            return self.predict(global_features, UnmaskedPoolFn.apply(point_features.float()))
+        return self.predict(global_features, None)

@@ -32,6 +32,46 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class SkinnyFwd(ctypes.Structure):
+    """Mirror of `wf3d_skinny_fwd_t`."""
+    _fields_ = [
+        ("X", c_void_p), ("ldx", c_int), ("W", c_void_p), ("ldw", c_int), ("bias", c_void_p),
+        ("Y", c_void_p), ("ldy", c_int), ("N", c_int), ("K", c_int),
+        ("gamma", c_void_p), ("beta", c_void_p), ("act", c_int),
+        ("in_part", c_void_p), ("in_nblk", c_int), ("mu", c_void_p), ("rs", c_void_p),
+        ("mu_out", c_void_p), ("rs_out", c_void_p),
+        ("in_addend", c_void_p), ("ld_in_addend", c_int),
+        ("out_addend", c_void_p), ("ld_out_addend", c_int),
+        ("stat_part", c_void_p),
+    ]
+
+
+class SkinnyBwd(ctypes.Structure):
+    """Mirror of `wf3d_skinny_bwd_t`."""
+    _fields_ = [
+        ("dY", c_void_p), ("lddy", c_int),
+        ("z", c_void_p), ("ldz", c_int), ("mu", c_void_p), ("rs", c_void_p), ("rowpart", c_void_p), ("rowpart_nblk", c_int),
+        ("W", c_void_p), ("ldw", c_int), ("N", c_int), ("K", c_int),
+        ("X", c_void_p), ("ldx", c_int),
+        ("xmu", c_void_p), ("xrs", c_void_p), ("xgamma", c_void_p), ("xbeta", c_void_p), ("xact", c_int),
+        ("xadd", c_void_p), ("ldxadd", c_int),
+        ("dW", c_void_p), ("lddw", c_int), ("db", c_void_p),
+        ("slabs", c_void_p), ("nc", c_int),
+    ]
+
+
+class SkinnyRed(ctypes.Structure):
+    """Mirror of `wf3d_skinny_red_t`."""
+    _fields_ = [
+        ("slabs", c_void_p * 3), ("nslab", c_int * 3),
+        ("extra", c_void_p), ("ldextra", c_int), ("K", c_int),
+        ("dh", c_void_p), ("lddh", c_int),
+        ("z", c_void_p), ("ldz", c_int), ("mu", c_void_p), ("rs", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("act", c_int),
+        ("G", c_void_p), ("ldg", c_int), ("dgamma", c_void_p), ("dbeta", c_void_p), ("rowpart", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/wf3d.h declares
 SIGNATURES = {
     "wf3d_version": (c_int, []),
@@ -61,10 +101,12 @@ SIGNATURES = {
     "wf3d_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_point_valid": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_pool4_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "wf3d_pool4_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wf3d_pool4_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_pool4_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wf3d_pool4_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                               c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_pool4_bwd_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_first_layer_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf3d_ln_act_bwd_first_ws_bytes": (c_size_t, [c_int, c_int]),
@@ -80,8 +122,8 @@ SIGNATURES = {
     "wf3d_rowdot_act_bwd_ws_bytes": (c_size_t, [c_int, c_int]),
     "wf3d_rowdot_act_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wf3d_pool4_bwd_sx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_pool4_bwd_sx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_edge_gather_verts": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p,
@@ -111,6 +153,11 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                 c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                 c_void_p]),
+    "wf3d_skinny_ok": (c_int, [c_int, c_int]),
+    "wf3d_skinny_fwd": (c_int, [ctypes.POINTER(SkinnyFwd), c_int, c_int, c_float, c_void_p]),
+    "wf3d_skinny_slab_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wf3d_skinny_bwd": (c_int, [ctypes.POINTER(SkinnyBwd), c_int, c_int, c_void_p]),
+    "wf3d_skinny_reduce": (c_int, [ctypes.POINTER(SkinnyRed), c_int, c_void_p]),
     "wf3d_edge_prob_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -15,6 +15,7 @@ normalised activations never exist in memory.
 import torch
 
 from . import config, ops
+from . import skinny as sk
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, NN, NT, TN, Pro
 
 
@@ -60,11 +61,11 @@ def _wgrad_tn(dz_s, h_s):
 
 class EncoderFn(torch.autograd.Function):
     """x[B,N,Din], params -> (pooled[B,2C] = [masked max | masked mean], point_features[B,N,C],
-    umean[B,C], umax[B,C]).
+    upooled[B,2C] = [unmasked mean | unmasked max]).
 
     params = [W_i, b_i, gamma_i, beta_i]*n_hidden + [W_out, b_out]   (the per-point shared MLP)
-    umean/umax are the UNMASKED pools the vertex head needs (VertexPredictor.py:86-87), produced
-    by the same pass as the masked ones.  The fusion MLP is its own Function (FusionFn) so that
+    upooled holds the UNMASKED pools the vertex head needs, already in its concatenation order
+    (VertexPredictor.py:86-88), produced by the same pass as the masked ones.  The fusion MLP is its own Function (FusionFn) so that
     its gradients are handed to autograd — and to the data-parallel reducer — before the long
     per-point backward starts.
 
@@ -115,31 +116,33 @@ class EncoderFn(torch.autograd.Function):
             a = z
         del a_s
         C = pf.shape[1]
-        mmax, mavg, umean, umax, arg_m, arg_u, cnt = ops.pool4_fwd(pf.view(B, N, C), valid)
-        pooled = torch.cat([mmax, mavg], dim=1)                           # max first (PointNetEncoder.py:115)
+        po = ops.pool4_fwd(pf.view(B, N, C), valid, packed=True)          # [max | avg] (PointNetEncoder.py:115), [mean | max]
         ctx.n_hidden, ctx.dims, ctx.split = n_hidden, (B, N, C), split
         ctx.params = params
-        ctx.saved = (x2, valid, zs, stats, hs, arg_m, arg_u, cnt)
+        ctx.saved = (x2, valid, zs, stats, hs, po.arg_m, po.arg_u, po.cnt)
+        ctx.nvalid = po.nvalid
         # unused outputs (point_features when only its pools are consumed) must not come back as 268 MB of zeros
         ctx.set_materialize_grads(False)
         pf3 = pf.view(B, N, C)
-        return pooled, pf3, umean, umax
+        return po.masked, pf3, po.unmasked
 
     @staticmethod
-    def backward(ctx, dpooled, dpf, dumean, dumax):
+    def backward(ctx, dpooled, dpf, dupooled):
         nh, (B, N, C), split = ctx.n_hidden, ctx.dims, ctx.split
         M = B * N
         params = ctx.params
         x2, valid, zs, stats, hs, arg_m, arg_u, cnt = _saved(ctx)
         grads = [None] * len(params)
-        dmmax = dpooled[:, :C].contiguous() if dpooled is not None else None
-        dmavg = dpooled[:, C:].contiguous() if dpooled is not None else None
+        # the pooled cotangents are read as strided halves of the [B, 2C] gradients: no copies
+        dmmax = dmavg = dumean = dumax = None
+        if dpooled is not None:
+            dpooled = dpooled if dpooled.stride(1) == 1 else dpooled.contiguous()
+            dmmax, dmavg = dpooled[:, :C], dpooled[:, C:]
+        if dupooled is not None:
+            dupooled = dupooled if dupooled.stride(1) == 1 else dupooled.contiguous()
+            dumean, dumax = dupooled[:, :C], dupooled[:, C:]
         if dpf is not None:
             dpf = dpf.contiguous()
-        if dumean is not None:
-            dumean = dumean.contiguous()
-        if dumax is not None:
-            dumax = dumax.contiguous()
         # output layer: with both of its consumers on the split path dz goes straight out as an sx8 operand
         # and its column sum (the bias gradient) follows from the [B, C] cotangents
         W_out = params[4 * nh]
@@ -147,7 +150,7 @@ class EncoderFn(torch.autograd.Function):
                      and ops.gemm_split_tn_shape_ok(M, C, hs[nh - 1].shape[1], C, hs[nh - 1].stride(0)))
         if out_split:
             dz, dz_s = None, ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C, sx8=True).view(M, C)
-            grads[4 * nh + 1] = ops.pool4_bwd_colsum(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C)
+            grads[4 * nh + 1] = ops.pool4_bwd_colsum(ctx.nvalid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C)
         else:
             dz = ops.pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf, B, N, C).view(M, C)
             dz_s = None
@@ -203,17 +206,29 @@ class EncoderFn(torch.autograd.Function):
 
 class FusionFn(torch.autograd.Function):
     """pooled[B,2C] -> global[B,C]: feature_fusion (PointNetEncoder.py:57-65,116).
-    params = [F0w, F0b, F1g, F1b, F3w, F3b, F4g, F4b, F6w, F6b]"""
+    params = [F0w, F0b, F1g, F1b, F3w, F3b, F4g, F4b, F6w, F6b]
+
+    B <= 32 rows: three launches of the weight-streaming skinny kernel forward, six backward
+    (csrc/skinny.hip); otherwise the generic GEMM path."""
 
     @staticmethod
     def forward(ctx, pooled, *F):
-        pooled = pooled.contiguous()
-        f0 = ops.gemm(pooled, F[0], NT, bias=F[1])
-        s0 = ops.row_stats(f0)
-        f3 = ops.gemm(f0, F[4], NT, bias=F[5], pro=Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
-        s3 = ops.row_stats(f3)
-        gl = ops.gemm(f3, F[8], NT, bias=F[9], pro=Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
-        ctx.params, ctx.saved = F, (pooled, f0, s0, f3, s3)
+        pooled = pooled if pooled.stride(1) == 1 else pooled.contiguous()
+        M = pooled.shape[0]
+        ctx.params = F
+        ctx.skinny = sk.ok(M, F[0], F[4], F[8]) and F[0].shape[0] % 16 == 0 and F[4].shape[0] % 16 == 0 \
+            and pooled.stride(0) % 4 == 0
+        if ctx.skinny:
+            (f0, p0, _), = sk.fwd(M, sk.Fwd(pooled, F[0], F[1], stats=True))
+            (f3, p3, s0), = sk.fwd(M, sk.Fwd(f0, F[4], F[5], ln=sk.LNIn(F[2], F[3], ACT_RELU, part=p0), stats=True))
+            (gl, _, s3), = sk.fwd(M, sk.Fwd(f3, F[8], F[9], ln=sk.LNIn(F[6], F[7], ACT_RELU, part=p3)))
+        else:
+            f0 = ops.gemm(pooled, F[0], NT, bias=F[1])
+            s0 = ops.row_stats(f0)
+            f3 = ops.gemm(f0, F[4], NT, bias=F[5], pro=Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
+            s3 = ops.row_stats(f3)
+            gl = ops.gemm(f3, F[8], NT, bias=F[9], pro=Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
+        ctx.saved = (pooled, f0, s0, f3, s3)
         return gl
 
     @staticmethod
@@ -222,12 +237,23 @@ class FusionFn(torch.autograd.Function):
         pooled, f0, s0, f3, s3 = _saved(ctx)
         G = [None] * 10
         dgl = dgl.contiguous()
-        G[9] = ops.colsum(dgl)
-        G[8], dh = _lin_bwd(dgl, f3, F[8], Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
-        dz, G[6], G[7], G[5] = ops.ln_act_bwd(dh, f3, s3[0], s3[1], F[6], F[7], ACT_RELU, inplace=True)
-        G[4], dh = _lin_bwd(dz, f0, F[4], Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
-        dz, G[2], G[3], G[1] = ops.ln_act_bwd(dh, f0, s0[0], s0[1], F[2], F[3], ACT_RELU, inplace=True)
-        G[0], dpooled = _lin_bwd(dz, pooled, F[0], None)
+        if ctx.skinny:
+            M = dgl.shape[0]
+            l3 = sk.LNIn(F[6], F[7], ACT_RELU, mu=s3[0], rs=s3[1])
+            l0 = sk.LNIn(F[2], F[3], ACT_RELU, mu=s0[0], rs=s0[1])
+            (G[8], G[9], sl), = sk.bwd(M, sk.Bwd(dgl, F[8], f3, x_ln=l3))
+            _, g3, G[6], G[7], rp3 = sk.reduce(M, F[8].shape[1], [sl], want_dh=False, ln=(f3, s3[0], s3[1], F[6], F[7], ACT_RELU))
+            (G[4], G[5], sl), = sk.bwd(M, sk.Bwd(g3, F[4], f0, ln_out=sk.LNOut(f3, s3[0], s3[1], rp3), x_ln=l0))
+            _, g0, G[2], G[3], rp0 = sk.reduce(M, F[4].shape[1], [sl], want_dh=False, ln=(f0, s0[0], s0[1], F[2], F[3], ACT_RELU))
+            (G[0], G[1], sl), = sk.bwd(M, sk.Bwd(g0, F[0], pooled, ln_out=sk.LNOut(f0, s0[0], s0[1], rp0)))
+            dpooled, *_ = sk.reduce(M, F[0].shape[1], [sl])
+        else:
+            G[9] = ops.colsum(dgl)
+            G[8], dh = _lin_bwd(dgl, f3, F[8], Pro(ACT_RELU, s3[0], s3[1], F[6], F[7]))
+            dz, G[6], G[7], G[5] = ops.ln_act_bwd(dh, f3, s3[0], s3[1], F[6], F[7], ACT_RELU, inplace=True)
+            G[4], dh = _lin_bwd(dz, f0, F[4], Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
+            dz, G[2], G[3], G[1] = ops.ln_act_bwd(dh, f0, s0[0], s0[1], F[2], F[3], ACT_RELU, inplace=True)
+            G[0], dpooled = _lin_bwd(dz, pooled, F[0], None)
         ctx.saved = None
         return (dpooled, *G)
 
@@ -236,34 +262,54 @@ class FusionFn(torch.autograd.Function):
 # Vertex head
 # ===========================================================================
 class VertexFn(torch.autograd.Function):
-    """(g[B,C], umean[B,C]|None, umax[B,C]|None, params) -> (o[B,V,vd], exist[B,V], counts[B] int64)
+    """(g[B,C], upooled[B,2C] = [mean | max] or None, params) -> (o[B,V,vd], exist[B,V], counts[B] int64)
 
-    params = [W1,b1,g1,be1, W2,b2,g2,be2, W3,b3,g3,be3, W4,b4,g4,be4, Wf,bf, Wr1,br1, Wr2,br2, (Wpp,bpp)]"""
+    params = [W1,b1,g1,be1, W2,b2,g2,be2, W3,b3,g3,be3, W4,b4,g4,be4, Wf,bf, Wr1,br1, Wr2,br2, (Wpp,bpp)]
+
+    B <= 32 rows: six weight-streaming launches forward (the three Linears that read `e` share one; the residual sums
+    c = relu(LN(z3)) + r1, d = relu(LN(z4)) + r2 are applied on load and never materialised), thirteen backward
+    (csrc/skinny.hip); otherwise the generic GEMM path."""
 
     @staticmethod
-    def forward(ctx, g, umean, umax, V, vd, *params):
+    def forward(ctx, g, upooled, V, vd, *params):
         g = g.contiguous()
         B = g.shape[0]
         (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4, g4, be4, Wf, bf, Wr1, br1, Wr2, br2) = params[:22]
-        pooled = None
-        if umean is not None:
-            Wpp, bpp = params[22:24]
-            pooled = torch.cat([umean, umax], dim=1)                      # mean first (VertexPredictor.py:88)
-            e = ops.gemm(pooled, Wpp, NT, bias=bpp, addend=g)
+        if upooled is not None:
+            upooled = upooled if upooled.stride(1) == 1 else upooled.contiguous()
+        mats = [W1, W2, W3, W4, Wf, Wr1, Wr2] + ([params[22]] if upooled is not None else [])
+        ctx.skinny = sk.ok(B, *mats) and all(w.shape[0] % 16 == 0 for w in (W1, W2, W3, W4)) \
+            and (upooled is None or upooled.stride(0) % 4 == 0)
+        if ctx.skinny:
+            if upooled is not None:
+                (e, _, _), = sk.fwd(B, sk.Fwd(upooled, params[22], params[23], out_add=g))     # enhanced = g + proj (:99-100)
+            else:
+                e = g
+            (z1, p1, _), (r1, _, _), (r2, _, _) = sk.fwd(B, sk.Fwd(e, W1, b1, stats=True), sk.Fwd(e, Wr1, br1), sk.Fwd(e, Wr2, br2))
+            (z2, p2, s1), = sk.fwd(B, sk.Fwd(z1, W2, b2, ln=sk.LNIn(g1, be1, ACT_RELU, part=p1), stats=True))
+            (z3, p3, s2), = sk.fwd(B, sk.Fwd(z2, W3, b3, ln=sk.LNIn(g2, be2, ACT_RELU, part=p2), stats=True))
+            # residual after the ReLU (:110,:114), applied on load
+            (z4, p4, s3), = sk.fwd(B, sk.Fwd(z3, W4, b4, ln=sk.LNIn(g3, be3, ACT_RELU, part=p3), in_add=r1, stats=True))
+            (o, _, s4), = sk.fwd(B, sk.Fwd(z4, Wf, bf, ln=sk.LNIn(g4, be4, ACT_RELU, part=p4), in_add=r2))
+            c, d = r1, r2
         else:
-            e = g
-        z1 = ops.gemm(e, W1, NT, bias=b1); s1 = ops.row_stats(z1)
-        z2 = ops.gemm(z1, W2, NT, bias=b2, pro=Pro(ACT_RELU, s1[0], s1[1], g1, be1)); s2 = ops.row_stats(z2)
-        z3 = ops.gemm(z2, W3, NT, bias=b3, pro=Pro(ACT_RELU, s2[0], s2[1], g2, be2)); s3 = ops.row_stats(z3)
-        r1 = ops.gemm(e, Wr1, NT, bias=br1)
-        c = ops.ln_act_apply(z3, s3[0], s3[1], g3, be3, ACT_RELU, addend=r1)   # residual after ReLU (:110)
-        z4 = ops.gemm(c, W4, NT, bias=b4); s4 = ops.row_stats(z4)
-        r2 = ops.gemm(e, Wr2, NT, bias=br2)
-        d = ops.ln_act_apply(z4, s4[0], s4[1], g4, be4, ACT_RELU, addend=r2)
-        o = ops.gemm(d, Wf, NT, bias=bf)
+            if upooled is not None:
+                e = ops.gemm(upooled, params[22], NT, bias=params[23], addend=g)
+            else:
+                e = g
+            z1 = ops.gemm(e, W1, NT, bias=b1); s1 = ops.row_stats(z1)
+            z2 = ops.gemm(z1, W2, NT, bias=b2, pro=Pro(ACT_RELU, s1[0], s1[1], g1, be1)); s2 = ops.row_stats(z2)
+            z3 = ops.gemm(z2, W3, NT, bias=b3, pro=Pro(ACT_RELU, s2[0], s2[1], g2, be2)); s3 = ops.row_stats(z3)
+            r1 = ops.gemm(e, Wr1, NT, bias=br1)
+            c = ops.ln_act_apply(z3, s3[0], s3[1], g3, be3, ACT_RELU, addend=r1)   # residual after ReLU (:110)
+            z4 = ops.gemm(c, W4, NT, bias=b4); s4 = ops.row_stats(z4)
+            r2 = ops.gemm(e, Wr2, NT, bias=br2)
+            d = ops.ln_act_apply(z4, s4[0], s4[1], g4, be4, ACT_RELU, addend=r2)
+            o = ops.gemm(d, Wf, NT, bias=bf)
         exist, counts = ops.vertex_finalize_fwd(o, V, vd)
         ctx.params, ctx.dims = params, (B, V, vd)
-        ctx.saved = (pooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d)
+        # skinny path: c / d hold r1 / r2 (the sums are rebuilt on load)
+        ctx.saved = (upooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d)
         ctx.save_for_backward(exist)
         ctx.mark_non_differentiable(counts)
         return o.view(B, V, vd), exist, counts
@@ -278,6 +324,32 @@ class VertexFn(torch.autograd.Function):
         G = [None] * len(params)
         do = ops.vertex_finalize_bwd(exist, dexist.contiguous() if dexist is not None else None,
                                      do3.contiguous() if do3 is not None else None, B, V, vd)
+        if ctx.skinny:
+            r1, r2 = c, d
+            R = ACT_RELU
+            ln = [None, sk.LNIn(g1, be1, R, mu=s1[0], rs=s1[1]), sk.LNIn(g2, be2, R, mu=s2[0], rs=s2[1]),
+                  sk.LNIn(g3, be3, R, mu=s3[0], rs=s3[1]), sk.LNIn(g4, be4, R, mu=s4[0], rs=s4[1])]
+            # final layer: input d = relu(LN(z4)) + r2
+            (G[16], G[17], sl), = sk.bwd(B, sk.Bwd(do, Wf, z4, x_ln=ln[4], x_add=r2))
+            dd, G4, G[14], G[15], rp4 = sk.reduce(B, Wf.shape[1], [sl], ln=(z4, s4[0], s4[1], g4, be4, R))
+            # residual_proj2 (plain dz = dd) and vertex_mlp4 (input c = relu(LN(z3)) + r1) in one launch
+            (G[20], G[21], sl_e2), (G[12], G[13], sl) = sk.bwd(
+                B, sk.Bwd(dd, Wr2, e), sk.Bwd(G4, W4, z3, ln_out=sk.LNOut(z4, s4[0], s4[1], rp4), x_ln=ln[3], x_add=r1))
+            dc, G3, G[10], G[11], rp3 = sk.reduce(B, W4.shape[1], [sl], ln=(z3, s3[0], s3[1], g3, be3, R))
+            (G[18], G[19], sl_e1), (G[8], G[9], sl) = sk.bwd(
+                B, sk.Bwd(dc, Wr1, e), sk.Bwd(G3, W3, z2, ln_out=sk.LNOut(z3, s3[0], s3[1], rp3), x_ln=ln[2]))
+            _, G2, G[6], G[7], rp2 = sk.reduce(B, W3.shape[1], [sl], want_dh=False, ln=(z2, s2[0], s2[1], g2, be2, R))
+            (G[4], G[5], sl), = sk.bwd(B, sk.Bwd(G2, W2, z1, ln_out=sk.LNOut(z2, s2[0], s2[1], rp2), x_ln=ln[1]))
+            _, G1, G[2], G[3], rp1 = sk.reduce(B, W2.shape[1], [sl], want_dh=False, ln=(z1, s1[0], s1[1], g1, be1, R))
+            (G[0], G[1], sl_e0), = sk.bwd(B, sk.Bwd(G1, W1, e, ln_out=sk.LNOut(z1, s1[0], s1[1], rp1)))
+            de, *_ = sk.reduce(B, W1.shape[1], [sl_e0, sl_e1, sl_e2])
+            dupooled = None
+            if pooled is not None:
+                Wpp = params[22]
+                (G[22], G[23], sl), = sk.bwd(B, sk.Bwd(de, Wpp, pooled))
+                dupooled, *_ = sk.reduce(B, Wpp.shape[1], [sl])
+            ctx.saved = None
+            return (de, dupooled, None, None, *G)
         G[17] = ops.colsum(do)
         G[16], dd = _lin_bwd(do, d, Wf, None)
         # d = relu(LN(z4)) + r2
@@ -297,16 +369,14 @@ class VertexFn(torch.autograd.Function):
         dz1, G[2], G[3], G[1] = ops.ln_act_bwd(dh, z1, s1[0], s1[1], g1, be1, ACT_RELU, inplace=True)
         G[0] = ops.gemm(dz1, e, TN)
         ops.gemm(dz1, W1, NN, out=de, accumulate=True)
-        dumean = dumax = None
+        dupooled = None
         if pooled is not None:
             Wpp = params[22]
-            C = pooled.shape[1] // 2
             G[23] = ops.colsum(de)
             G[22] = ops.gemm(de, pooled, TN)
-            dpooled = ops.gemm(de, Wpp, NN)
-            dumean, dumax = dpooled[:, :C], dpooled[:, C:]
+            dupooled = ops.gemm(de, Wpp, NN)
         ctx.saved = None
-        return (de, dumean, dumax, None, None, *G)
+        return (de, dupooled, None, None, *G)
 
 
 # ===========================================================================
@@ -498,22 +568,21 @@ def edge_index_lists(counts):
 
 
 class UnmaskedPoolFn(torch.autograd.Function):
-    """point_features[B,N,C] -> (mean_n, max_n): the vertex head's own pooling
-    (VertexPredictor.py:86-87) when it is used outside PointCloudToWireframe."""
+    """point_features[B,N,C] -> [mean_n | max_n] as one [B, 2C] tensor: the vertex head's own pooling and its
+    concatenation (VertexPredictor.py:86-88) when it is used outside PointCloudToWireframe."""
 
     @staticmethod
     def forward(ctx, pf):
         pf = pf.contiguous()
         B, N, C = pf.shape
         ones = torch.ones(B * N, dtype=torch.float32, device=pf.device)
-        _, _, umean, umax, arg_m, arg_u, cnt = ops.pool4_fwd(pf, ones)
-        ctx.dims, ctx.saved = (B, N, C), (ones, cnt, arg_m, arg_u)
-        return umean, umax
+        po = ops.pool4_fwd(pf, ones, packed=True)
+        ctx.dims, ctx.saved = (B, N, C), (ones, po.cnt, po.arg_m, po.arg_u)
+        return po.unmasked
 
     @staticmethod
-    def backward(ctx, dumean, dumax):
+    def backward(ctx, dup):
         B, N, C = ctx.dims
         ones, cnt, arg_m, arg_u = _saved(ctx)
-        dumean = dumean.contiguous() if dumean is not None else None
-        dumax = dumax.contiguous() if dumax is not None else None
-        return ops.pool4_bwd(ones, cnt, arg_m, arg_u, None, None, dumean, dumax, None, B, N, C)
+        dup = dup if dup.stride(1) == 1 else dup.contiguous()
+        return ops.pool4_bwd(ones, cnt, arg_m, arg_u, None, None, dup[:, :C], dup[:, C:], None, B, N, C)

@@ -257,54 +257,78 @@ def point_valid(x):
     return valid
 
 
-def pool4_fwd(pf, valid):
-    """pf [B,N,C], valid [B*N] -> (mmax, mavg, umean, umax, arg_m, arg_u, cnt)."""
+class PoolOut:
+    """Everything one pooling pass yields.  `masked` = [masked max | masked mean] and `unmasked` = [mean | max] are
+    [B, 2C] tensors in the order the reference concatenates them (PointNetEncoder.py:115, VertexPredictor.py:88);
+    mmax/mavg/umean/umax are views of their halves."""
+    __slots__ = ("masked", "unmasked", "mmax", "mavg", "umean", "umax", "arg_m", "arg_u", "cnt", "nvalid")
+
+
+def pool4_fwd(pf, valid, packed=False):
+    """pf [B,N,C], valid [B*N] -> (mmax, mavg, umean, umax, arg_m, arg_u, cnt), or a PoolOut with packed=True."""
     _need_cuda(pf, valid)
     if not pf.is_contiguous():
         raise RuntimeError("wf3d.pool4_fwd: contiguous point_features required")
     B, N, C = pf.shape
     dev = pf.device
-    f = lambda: torch.empty(B, C, dtype=torch.float32, device=dev)   # noqa: E731
-    mmax, mavg, umean, umax = f(), f(), f(), f()
-    arg_m = torch.empty(B, C, dtype=torch.int32, device=dev)
-    arg_u = torch.empty(B, C, dtype=torch.int32, device=dev)
-    cnt = torch.empty(B, dtype=torch.float32, device=dev)
+    o = PoolOut()
+    o.masked = torch.empty(B, 2 * C, dtype=torch.float32, device=dev)
+    o.unmasked = torch.empty(B, 2 * C, dtype=torch.float32, device=dev)
+    o.mmax, o.mavg = o.masked[:, :C], o.masked[:, C:]
+    o.umean, o.umax = o.unmasked[:, :C], o.unmasked[:, C:]
+    o.arg_m = torch.empty(B, C, dtype=torch.int32, device=dev)
+    o.arg_u = torch.empty(B, C, dtype=torch.int32, device=dev)
+    cn = torch.empty(2, B, dtype=torch.float32, device=dev)
+    o.cnt, o.nvalid = cn[0], cn[1]
     lib = _lib.load()
     ws = scratch(lib.wf3d_pool4_ws_bytes(B, N, C), dev)
-    check(lib.wf3d_pool4_fwd(_p(pf), _p(valid), B, N, C, _p(mmax), _p(mavg), _p(umean), _p(umax), _p(arg_m),
-                             _p(arg_u), _p(cnt), _p(ws), ws.numel(), _stream()), "pool4_fwd")
-    return mmax, mavg, umean, umax, arg_m, arg_u, cnt
+    check(lib.wf3d_pool4_fwd(_p(pf), _p(valid), B, N, C, _p(o.mmax), _p(o.mavg), _p(o.umean), _p(o.umax), 2 * C,
+                             _p(o.arg_m), _p(o.arg_u), _p(o.cnt), _p(o.nvalid), _p(ws), ws.numel(), _stream()), "pool4_fwd")
+    if packed:
+        return o
+    return o.mmax, o.mavg, o.umean, o.umax, o.arg_m, o.arg_u, o.cnt
+
+
+def _pair_ld(a, b, what):
+    """Row stride shared by a pair of [B, C] cotangents (the two halves of one [B, 2C] gradient, or contiguous)."""
+    ld = None
+    for t in (a, b):
+        if t is None:
+            continue
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"wf3d.pool4_bwd: {what} cotangents need unit inner stride")
+        s = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+        if ld is not None and s != ld:
+            raise RuntimeError(f"wf3d.pool4_bwd: the two {what} cotangents must share one row stride")
+        ld = s
+    return ld or 0
 
 
 def pool4_bwd(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C, sx8=False):
-    """sx8=True: the result is written as an sx8 split operand (C % 8 == 0) instead of fp32."""
+    """sx8=True: the result is written as an sx8 split operand (C % 8 == 0) instead of fp32.  The cotangents may be
+    strided views (halves of a [B, 2C] gradient)."""
     _need_cuda(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct)
-    for t in (dmmax, dmavg, dumean, dumax, dpf_direct):
-        if t is not None and not t.is_contiguous():
-            raise RuntimeError("wf3d.pool4_bwd: contiguous cotangents required")
+    if dpf_direct is not None and not dpf_direct.is_contiguous():
+        raise RuntimeError("wf3d.pool4_bwd: contiguous dpf_direct required")
+    ldm, ldu = _pair_ld(dmmax, dmavg, "masked"), _pair_ld(dumean, dumax, "unmasked")
     dpf = torch.empty(B, N, C, dtype=torch.float32, device=valid.device)
     fn = _lib.load().wf3d_pool4_bwd_sx8 if sx8 else _lib.load().wf3d_pool4_bwd
-    check(fn(_p(valid), _p(cnt), _p(arg_m), _p(arg_u), _p(dmmax), _p(dmavg), _p(dumean), _p(dumax), _p(dpf_direct),
-             B, N, C, _p(dpf), _stream()), "pool4_bwd")
+    check(fn(_p(valid), _p(cnt), _p(arg_m), _p(arg_u), _p(dmmax), _p(dmavg), ldm, _p(dumean), _p(dumax), ldu,
+             _p(dpf_direct), B, N, C, _p(dpf), _stream()), "pool4_bwd")
     return dpf
 
 
-def pool4_bwd_colsum(valid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C):
+def pool4_bwd_colsum(nvalid, cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, B, N, C):
     """Column sums over all B*N rows of what pool4_bwd writes, from the [B, C] cotangents alone:
-    sum_n of  valid*dmavg/cnt + dumean/N + [n==arg_m]*dmmax + [n==arg_u]*dumax  (+ dpf_direct)."""
-    dev = valid.device
-    acc = torch.zeros(B, C, dtype=torch.float32, device=dev)
-    if dmavg is not None:
-        acc += dmavg * (valid.view(B, N).sum(1) / cnt.view(B)).unsqueeze(1)
-    if dumean is not None:
-        acc += dumean
-    if dmmax is not None:
-        acc += torch.where(arg_m >= 0, dmmax, torch.zeros_like(dmmax))
-    if dumax is not None:
-        acc += torch.where(arg_u >= 0, dumax, torch.zeros_like(dumax))
-    out = acc.sum(0)
-    if dpf_direct is not None:
-        out = out + colsum(dpf_direct.view(B * N, C))
+    sum_n of  valid*dmavg/cnt + dumean/N + [n==arg_m]*dmmax + [n==arg_u]*dumax  (+ dpf_direct).
+    nvalid [B] = number of valid points per cloud (PoolOut.nvalid)."""
+    _need_cuda(cnt, arg_m, arg_u, dmmax, dmavg, dumean, dumax, dpf_direct, nvalid)
+    ldm, ldu = _pair_ld(dmmax, dmavg, "masked"), _pair_ld(dumean, dumax, "unmasked")
+    out = torch.empty(C, dtype=torch.float32, device=cnt.device)
+    check(_lib.load().wf3d_pool4_bwd_bias(_p(cnt), _p(nvalid), _p(arg_m), _p(arg_u), _p(dmmax), _p(dmavg), ldm, _p(dumean),
+                                          _p(dumax), ldu, B, C, _p(out), _stream()), "pool4_bwd_bias")
+    if dpf_direct is not None:              # point_features itself received a gradient (never on the model's own path)
+        out += colsum(dpf_direct.view(B * N, C))
     return out
 
 
