@@ -34,6 +34,8 @@ CONFIGS = {
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA (never the 2:1-sparsity figure)
+HBM_PEAK_GBS = 8000.0               # HBM3E spec (6.3 TB/s measured on a float4 copy, same guide)
+PROFILE_TAG = "r02"                 # rocprofv3 summaries of this round's build under profiles/
 SEED = 1234
 
 
@@ -61,53 +63,78 @@ def make_inputs(B, N, V, rank, device):
     return x.to(device), counts.to(device), {k: v.to(device) for k, v in cot.items()}
 
 
-class GemmTimer:
-    """HIP-event timing of the dominant kernel's launches inside the timed region, on the
-    stream they are launched on (torch's current stream): the 128x128 GEMM tile of
-    wf3d_gemm_split (bf16x3 mode) or wf3d_gemm (fp32 mode), launches >= min_flops."""
+class OpTimer:
+    """HIP-event timing of individual C-ABI calls inside the timed region, on the stream they are launched on (torch's
+    current stream).  Every wrapped call is bracketed by two events; `work(args, result)` gives its algorithmic
+    (flops, bytes).  Groups:
+      gemm   ops.gemm_split     forward + dgrad GEMMs of the per-point MLP  -> gemm_split_x16p_kernel (the dominant kernel)
+      wgrad  ops.gemm_split_tn  weight-gradient GEMMs                        -> gemm_split_x16_kernel<true> + split_reduce
+      rows   ops.ln_prep / ln_act_bwd / first_layer_fwd / ln_act_bwd_first   LayerNorm passes between the GEMMs (HBM-bound)
+      pool   ops.pool4_fwd / pool4_bwd                                       the 4-way pool and its scatter (HBM-bound)
+    Only launches above `min_flops` / `min_bytes` are timed (the encoder's; the heads' small ones are left alone)."""
 
-    def __init__(self, min_flops):
-        self.min_flops, self.recs = min_flops, []
+    def __init__(self, min_flops=1e11, min_bytes=1e8):
+        self.min_flops, self.min_bytes, self.recs, self._saved = min_flops, min_bytes, [], []
 
-    def _wrap(self, fn, dims):
+    def _wrap(self, mod, name, group, work):
+        fn = getattr(mod, name)
         timer = self
 
-        def timed(a, b, *args, **kw):
-            M, N, K = dims(a, b, *args)
-            fl = 2.0 * M * N * K
-            if fl < timer.min_flops:
-                return fn(a, b, *args, **kw)
+        def timed(*a, **kw):
+            fl, by = work(a, kw)
+            if fl < timer.min_flops and by < timer.min_bytes:
+                return fn(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = fn(a, b, *args, **kw)
+            out = fn(*a, **kw)
             e1.record()
-            timer.recs.append((e0, e1, fl))
+            timer.recs.append((group, name, e0, e1, fl, by))
             return out
 
-        return timed
+        self._saved.append((mod, name, fn))
+        setattr(mod, name, timed)
 
     def install(self, ops, split):
-        self._ops, self._orig = ops, (ops.gemm, ops.gemm_split)
+        el = lambda t: t.shape[0] * t.shape[1]                                     # noqa: E731
         if split:
-            # dominant kernel = gemm_split_x16p_kernel: the 8 forward + dgrad GEMMs of the per-point MLP
-            # (the 4 wgrad GEMMs run gemm_split_tn_kernel and are reported by rocprofv3 in profiles/)
-            ops.gemm_split = self._wrap(ops.gemm_split, lambda a, b: (a.shape[0], b.shape[0], a.shape[1]))
+            self._wrap(ops, "gemm_split", "gemm", lambda a, k: (2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1],
+                                                                4.0 * (el(a[0]) + el(a[1]) + a[0].shape[0] * a[1].shape[0])))
+            self._wrap(ops, "gemm_split_tn", "wgrad", lambda a, k: (2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1],
+                                                                    4.0 * (el(a[0]) + el(a[1]) + a[0].shape[1] * a[1].shape[1])))
         else:
-            def dims(a, b, layout):
+            def gw(a, k):
+                x, w, layout = a[0], a[1], a[2]
                 if layout == ops.TN:
-                    return a.shape[1], b.shape[1], a.shape[0]
-                if layout == ops.NN:
-                    return a.shape[0], b.shape[1], a.shape[1]
-                return a.shape[0], b.shape[0], a.shape[1]
-            ops.gemm = self._wrap(ops.gemm, dims)
+                    M, N, K = x.shape[1], w.shape[1], x.shape[0]
+                elif layout == ops.NN:
+                    M, N, K = x.shape[0], w.shape[1], x.shape[1]
+                else:
+                    M, N, K = x.shape[0], w.shape[0], x.shape[1]
+                return 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)
+            self._wrap(ops, "gemm", "gemm", gw)
+        # row passes: algorithmic bytes per element (DESIGN.md section 4): z read + h written; dh, z read + dz written
+        self._wrap(ops, "ln_prep", "rows", lambda a, k: (0.0, 8.0 * el(a[0])))
+        self._wrap(ops, "ln_act_bwd", "rows", lambda a, k: (0.0, (12.0 if k.get("dz_split") is None or not k.get("want_dz", True) else 16.0) * el(a[1])))
+        self._wrap(ops, "first_layer_fwd", "rows", lambda a, k: (0.0, 8.0 * a[0].shape[0] * a[1].shape[0]))
+        self._wrap(ops, "ln_act_bwd_first", "rows", lambda a, k: (0.0, 8.0 * el(a[1])))
+        self._wrap(ops, "pool4_fwd", "pool", lambda a, k: (0.0, 4.0 * a[0].numel()))
+        self._wrap(ops, "pool4_bwd", "pool", lambda a, k: (0.0, 4.0 * a[9] * a[10] * a[11]))
 
     def uninstall(self):
-        self._ops.gemm, self._ops.gemm_split = self._orig
+        for mod, name, fn in reversed(self._saved):
+            setattr(mod, name, fn)
+        self._saved = []
 
     def summary(self):
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.recs)
-        fl = sum(f for _, _, f in self.recs)
-        return len(self.recs), ms, fl
+        """group -> dict(launches, ms, flops, bytes, per-op ms)"""
+        out = {}
+        for group, name, e0, e1, fl, by in self.recs:
+            g = out.setdefault(group, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "ops": {}})
+            ms = e0.elapsed_time(e1)
+            g["launches"] += 1; g["ms"] += ms; g["flops"] += fl; g["bytes"] += by
+            o = g["ops"].setdefault(name, [0, 0.0, 0.0])
+            o[0] += 1; o[1] += ms; o[2] += by
+        return out
 
 
 def host_cores():
@@ -134,14 +161,15 @@ def host_cores():
     return min(n, int(os.environ.get("WF3D_CPU_THREADS", "16")))
 
 
-def cpu_baseline(model, N, V, seconds_budget=25.0):
+def cpu_baseline(model, cfg, N, V, seconds_budget=25.0):
     """The CPU oracle (oracle/reference_cpu.py, proven equal to the reference in
     the build container) timed on this box's host cores on a bounded sample of
-    the same workload: cfg2 shape at batch 4, 1 warm-up + up to 3 timed steps."""
+    the same workload: the benchmarked config's shape (N points, V vertices) at a reduced batch
+    (~1 s of CPU work per step), 1 warm-up + up to 3 timed steps."""
     from oracle import reference_cpu as oracle
     cores = host_cores()
     torch.set_num_threads(cores)
-    Bc = 4
+    Bc = {"cfg4": 1, "cfg5": 2, "cfg1": 1}.get(cfg, 4)
     P = oracle.params_from_module(model)
     g = torch.Generator().manual_seed(SEED)
     x = torch.randn(Bc, N, 8, generator=g)
@@ -164,7 +192,7 @@ def cpu_baseline(model, N, V, seconds_budget=25.0):
             break
     med = statistics.median(times)
     return {"value": Bc / med, "unit": "clouds/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/reference_cpu.py fwd+bwd, cfg2 shape N={N} V={V} at batch {Bc}, "
+            "sample": f"oracle/reference_cpu.py fwd+bwd, {cfg} shape N={N} V={V} at batch {Bc}, "
                       f"1 warm-up + {len(times)} timed steps, median {med * 1e3:.0f} ms/step, dropout 0"}
 
 
@@ -217,14 +245,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # all process-group setup happened in init_from_env(), before any kernel of ours ran on this rank
     for _ in range(args.warmup):
         step()
-    timer = GemmTimer(min_flops=1e11)     # the encoder's twelve >=137-GFLOP GEMM launches per step
+    if reducer is not None:
+        reducer.exposed_ms()                  # drop the warm-up records
+    timer = OpTimer()
     timer.install(ops, split)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     timer.uninstall()
@@ -234,16 +268,11 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
-        n_launch, gemm_ms, gemm_fl = timer.summary()
+        groups = timer.summary()
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         total_fl, enc_fl = algorithmic_flops_per_cloud(N, V)
-        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.config + ("" if split else "_fp32"), {}).get("gemm_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        g = groups.get("gemm", {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         if split:
             # bf16x3: every algorithmic product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
             peak, kern = BF16_MFMA_PEAK_TFLOPS, "gemm_split_x16p_kernel (persistent, 256x256x32 tile, LDS-DMA staged, 3 x v_mfma_f32_16x16x32_bf16 per product)"
@@ -252,12 +281,36 @@ def main():
         else:
             peak, kern = FP32_MFMA_PEAK_TFLOPS, "gemm_kernel<2,2,2,2> (128x128x32 v_mfma_f32_32x32x2_f32)"
             extra = {}
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                # HBM-side bytes come from rocprofv3 PMC passes, not from this run: see the committed profile
+                "traffic": None, "traffic_profile": f"profiles/{PROFILE_TAG}_pmc_summary.json ({args.config})",
+                "kernel": kern, "launches_timed": g["launches"], "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
+                "gemm_ms_per_step": g["ms"] / max(args.steps, 1),
+                "whole_step_tflops": total_fl * B * world * args.steps / dt / 1e12, **extra}
+        if "wgrad" in groups:
+            w = groups["wgrad"]
+            wa = w["flops"] / (w["ms"] * 1e-3) / 1e12
+            roof["wgrad"] = {"kernel": "gemm_split_x16_kernel<true> (+ split_reduce_kernel): dW = dz^T h on reduction-major sx8 operands",
+                             "bound": "mfma", "achieved": wa, "peak": peak, "unit": "TFLOP/s", "frac": wa / peak,
+                             "launches_timed": w["launches"], "ms_per_step": w["ms"] / args.steps}
+        hbm = {}
+        for grp, label in (("rows", "LayerNorm passes between the GEMMs"), ("pool", "4-way pool + its scatter")):
+            if grp in groups:
+                r = groups[grp]
+                gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                hbm[grp] = {"what": label, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": gbs / HBM_PEAK_GBS, "ms_per_step": r["ms"] / args.steps,
+                            "algorithmic_bytes_per_step": r["bytes"] / args.steps,
+                            "ops": {k: {"launches_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
+                                        "GB/s": v[2] / (v[1] * 1e-3) / 1e9} for k, v in r["ops"].items()}}
+        roof["hbm"] = hbm
         res = {
             "metric": "point-clouds/sec fwd+bwd",
             "value": B * world * args.steps / dt,
             "unit": "clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_median_hip_events": step_ms[len(step_ms) // 2],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3" if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N}x8 clouds, max_vertices={V}, batch {B}/GPU, train-mode fwd+bwd, "
@@ -267,13 +320,16 @@ def main():
                        "arithmetic": ("fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate "
                                       "(outputs within 1e-4 of the fp32 reference); heads and edge MLP on fp32 MFMA")
                        if split else "fp32 MFMA everywhere"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "kernel": kern,
-                         "launches_timed": n_launch, "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
-                         "whole_step_tflops": total_fl * B * world * args.steps / dt / 1e12, **extra},
+            "roofline": roof,
         }
+        if world > 1:
+            ex = sorted(reducer.exposed_ms())
+            res["rccl_ranks"] = torch.distributed.get_world_size()
+            res["dist_backend"] = torch.distributed.get_backend()
+            res["allreduce_exposed_ms"] = ex[len(ex) // 2] if ex else None
+            res["allreduce_buckets_mb"] = [round(nb / 2 ** 20, 1) for _, nb in reducer.bucket_summary()]
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, N, V)
+            res["cpu_baseline"] = cpu_baseline(model, args.config, N, V)
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -3,7 +3,8 @@
 committed summaries under profiles/ (round-tagged), and into
 profiles/pmc_summary.json, which bench.py reads for `roofline.traffic`.
 
-    python scripts/summarize_profiles.py r01
+    python scripts/summarize_profiles.py r02            # cfg2 (bench.py default)
+    python scripts/summarize_profiles.py r02_cfg5 cfg5  # another config: dirs gpurun_out/prof_r02_cfg5_*
 
 Inputs (written on the GPU box by the commands recorded in profiles/README.md):
     gpurun_out/prof_<tag>_trace*/**/_kernel_stats.csv   rocprofv3 --kernel-trace --stats
@@ -26,6 +27,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+CFG_DESC = {"cfg2": "B=32, N=4096, V=64", "cfg4": "B=8, N=16384, V=64", "cfg5": "B=32, N=4096, V=256"}[cfg]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -108,24 +111,46 @@ for name, ctrs in sq.items():
                       # effective clock under load (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE / 8 / wall
                       "effective_clock_ghz": gui / 8.0 / (dur_us * 1e3) if dur_us else None}
 summary["gemm_mfma"] = mfma
+# every kernel: MFMA pipe occupancy over all its launches, and HBM-side GB/s from the two byte passes
+per_kernel = {}
+for name, ctrs in sq.items():
+    busy = sum(v for v, d, _ in ctrs.get("SQ_VALU_MFMA_BUSY_CYCLES", []))
+    gui = sum(v for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []))
+    dur = sum(d for v, d, _ in ctrs.get("GRBM_GUI_ACTIVE", []))
+    n = len(ctrs.get("GRBM_GUI_ACTIVE", []))
+    if n and gui:
+        per_kernel[name] = {"launches": n, "avg_us": dur / n, "mfma_busy_frac": busy / (gui / 8.0 * 1024.0),
+                            "effective_clock_ghz": gui / 8.0 / (dur * 1e3)}
+for name in set(fetch) | set(write):
+    fv = fetch.get(name, {}).get("FETCH_SIZE", [])
+    wv = write.get(name, {}).get("WRITE_SIZE", [])
+    e = per_kernel.setdefault(name, {})
+    if fv:
+        e["read_bytes_avg"] = 2 * 1024 * sum(v for v, _, _ in fv) / len(fv)
+        e["read_pass_avg_us"] = sum(d for _, d, _ in fv) / len(fv)
+    if wv:
+        e["write_bytes_avg"] = 1024 * sum(v for v, _, _ in wv) / len(wv)
+        e["write_pass_avg_us"] = sum(d for _, d, _ in wv) / len(wv)
+    us = [e[k] for k in ("read_pass_avg_us", "write_pass_avg_us") if k in e]
+    if us:
+        e["hbm_GBps"] = (e.get("read_bytes_avg", 0.0) + e.get("write_bytes_avg", 0.0)) / (sum(us) / len(us) * 1e-6) / 1e9
+summary["per_kernel"] = per_kernel
+summary["config"] = cfg
 if gemm_fetch and gemm_write:
     rd = 2 * 1024 * sum(gemm_fetch) / len(gemm_fetch)
     wr = 1024 * sum(gemm_write) / len(gemm_write)
-    summary["cfg2"] = {"kernel": DOM, "gemm_launches": len(gemm_fetch), "gemm_read_bytes_per_launch": rd,
+    summary[cfg] = {"kernel": DOM, "gemm_launches": len(gemm_fetch), "gemm_read_bytes_per_launch": rd,
                        "gemm_write_bytes_per_launch": wr, "gemm_hbm_bytes_per_launch": rd + wr,
                        "correction": "read = 2 x FETCH_SIZE KiB (gfx950 16-B/lane streams), write = WRITE_SIZE KiB"}
 json.dump(summary, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
-if "cfg2" in summary:
-    json.dump({"cfg2": summary["cfg2"], "source": f"profiles/{tag}_pmc_summary.json"},
-              open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 
 with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary, round {tag} (cfg2: B=32, N=4096, V=64; dominant kernel `{DOM}`)\n\n")
+    f.write(f"# rocprofv3 summary, {tag} ({cfg}: {CFG_DESC}; dominant kernel `{DOM}`)\n\n")
     f.write("## kernel-trace --stats (3 timed + 1 warm-up steps)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for n, c, t, a, pc in stats_rows[:30]:
         f.write(f"| `{n}` | {c} | {t:.2f} | {a:.1f} | {pc:.1f} |\n")
-    if "cfg2" in summary:
-        c = summary["cfg2"]
+    if cfg in summary:
+        c = summary[cfg]
         f.write(f"\n## HBM-side traffic of the dominant kernel (`{DOM}`, launches >= {BIG_US:.0f} us)\n\n")
         f.write(f"launches {c['gemm_launches']}: read {c['gemm_read_bytes_per_launch'] / 1e6:.1f} MB + write "
                 f"{c['gemm_write_bytes_per_launch'] / 1e6:.1f} MB = {c['gemm_hbm_bytes_per_launch'] / 1e6:.1f} MB per launch "
@@ -135,4 +160,14 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
         for n, e in mfma.items():
             f.write(f"* `{n}`: {e['launches']} launches, busy fraction {e['mfma_busy_frac']:.3f}, effective clock "
                     f"{e['effective_clock_ghz']:.2f} GHz (GRBM_GUI_ACTIVE / 8 / wall)\n")
+    top = sorted(((e.get("avg_us", 0.0) * e.get("launches", 0), n, e) for n, e in per_kernel.items()), reverse=True)[:24]
+    if top:
+        f.write("\n## per kernel: MFMA pipe occupancy (SQ pass) and HBM-side bytes per launch (FETCH_SIZE x 2 x 1 KiB, WRITE_SIZE x 1 KiB; own passes)\n\n")
+        f.write("| kernel | launches | avg us | MFMA busy | clock GHz | read MB | write MB | GB/s |\n|---|---|---|---|---|---|---|---|\n")
+        for _, n, e in top:
+            fmt = lambda k, sc=1.0, nd=1: (f"{e[k] * sc:.{nd}f}" if k in e and e[k] is not None else "-")   # noqa: E731
+            f.write(f"| `{n}` | {e.get('launches', '-')} | {fmt('avg_us')} | {fmt('mfma_busy_frac', 1.0, 3)} | {fmt('effective_clock_ghz', 1.0, 2)} | "
+                    f"{fmt('read_bytes_avg', 1e-6)} | {fmt('write_bytes_avg', 1e-6)} | {fmt('hbm_GBps', 1.0, 0)} |\n")
+        f.write("\n(the x2 on FETCH_SIZE is the gfx950 correction for 16-B-per-lane coalesced streams, MI355X_MICROARCH.md section HBM; "
+                "kernels that read with narrower accesses are over-stated by it, Infinity-Cache hits are counted as fetches)\n")
 print(open(os.path.join(P, f"{tag}_summary.md")).read())

@@ -85,6 +85,83 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_late(rank, world, port, q):
+    """A parameter that starts receiving gradients only in a later step (its bucket would launch before that
+    gradient exists), and two backward() calls before one finish() (gradient accumulation): the reducer must
+    still hand every rank the mean of the FINAL per-rank gradients."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from wf3d import dist as wd
+    wd.init_from_env("cpu")
+    torch.manual_seed(5)
+    m = Toy()
+    wd.sync_parameters(m)
+    red = wd.GradReducer(m, bucket_mb=1.0)                            # one bucket per stage
+    torch.manual_seed(11 + rank)
+    X = torch.randn(4, 6)
+
+    def loss(use_spatial):
+        h = torch.relu(m.encoder["feature_fusion"](torch.relu(m.encoder["mlp"](X))))
+        v = torch.tanh(m.vertex_predictor(h))
+        o = m.edge_predictor["used"](v)
+        if use_spatial:
+            o = o + m.edge_predictor["spatial_proj"](v)
+        return o.square().sum()
+
+    def expect(fn):
+        ps = [p for p in m.parameters()]
+        gs = torch.autograd.grad(fn(), ps, allow_unused=True)
+        out = []
+        for g, p in zip(gs, ps):
+            g = torch.zeros_like(p) if g is None else g.clone()
+            dist.all_reduce(g)
+            out.append(g / world)
+        return out
+
+    for step, use_spatial in enumerate([False, False, True, True]):   # spatial_proj wakes up in step 2
+        want = expect(lambda: loss(use_spatial))
+        m.zero_grad()
+        loss(use_spatial).backward()
+        red.finish()
+        for p, w in zip(m.parameters(), want):
+            if p.grad is None:
+                assert float(w.abs().max()) == 0.0
+            else:
+                assert torch.allclose(p.grad, w, atol=1e-6), (step, (p.grad - w).abs().max())
+    # two micro-batches accumulated before one finish()
+    want = [2 * w for w in expect(lambda: loss(True))]
+    m.zero_grad()
+    loss(True).backward()
+    loss(True).backward()
+    red.finish()
+    for p, w in zip(m.parameters(), want):
+        assert torch.allclose(p.grad, w, atol=1e-5), (p.grad - w).abs().max()
+    q.put((rank, "ok", None))
+    dist.destroy_process_group()
+
+
+def _run2(target):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    res = []
+    while not q.empty():
+        res.append(q.get())
+    for p in procs:
+        assert p.exitcode == 0, f"worker exit {p.exitcode}"
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] == "ok" for r in res)
+    return res
+
+
+def test_grad_reducer_late_gradients_and_accumulation_world2_gloo():
+    _run2(_worker_late)
+
+
 def test_grad_reducer_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

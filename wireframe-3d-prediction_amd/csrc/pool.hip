@@ -3,10 +3,14 @@
 // The reference reads point_features four times (masked mean + masked max in
 // PointNetEncoder.py:103-111, unmasked mean + max in VertexPredictor.py:86-88);
 // here one streaming pass yields all four reductions plus the two arg-max index
-// vectors the backward scatter needs.  Thread = channel (coalesced 256-B rows
-// per wave), the N axis is split over blockIdx.y so that B*nsplit*C/256 >> 256
-// workgroups fill the chip; a tiny second kernel folds the splits in index
-// order (first-max tie rule of torch.max: smallest n wins).
+// vectors the backward scatter needs.
+//
+// pool4_partial_v4_kernel (C % 64 == 0): a wave reads 4 point rows x 64 channels per load instruction, 16 B per lane
+// (lane = row-in-group x float4 column), four loads in flight per lane; each lane folds its rows in registers, the
+// 4 row groups of a wave are folded by a WAVEFRONT SHUFFLE tree (xor 16, 32), the 4 waves of the workgroup by an
+// LDS tree; the N axis is split over blockIdx.y so that thousands of workgroups fill the chip, and a tiny second
+// kernel folds the splits.  Every fold keeps torch.max's first-max rule (equal values: the smaller n wins).
+// pool4_partial_kernel (any C): thread = channel, 4-byte loads — the fallback.
 #include "wf3d_common.h"
 
 namespace {
@@ -50,6 +54,101 @@ __global__ __launch_bounds__(256) void pool4_partial_kernel(const float* __restr
         part[((size_t)b * nsplit + sp) * C + c] = o;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt_part[b * nsplit + sp] = cnt;
+}
+
+struct Pool4 {                 // running state of 4 channels
+    f32x4 msum, usum, mmax, umax;
+    int am[4], au[4];
+};
+
+// fold `o` into `a`; on equal maxima the smaller point index wins (torch.max returns the first maximum)
+__device__ __forceinline__ void pool4_merge(Pool4& a, const Pool4& o) {
+    a.msum += o.msum;
+    a.usum += o.usum;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (o.au[e] >= 0 && (a.au[e] < 0 || o.umax[e] > a.umax[e] || (o.umax[e] == a.umax[e] && o.au[e] < a.au[e]))) {
+            a.umax[e] = o.umax[e]; a.au[e] = o.au[e];
+        }
+        if (o.am[e] >= 0 && (a.am[e] < 0 || o.mmax[e] > a.mmax[e] || (o.mmax[e] == a.mmax[e] && o.am[e] < a.am[e]))) {
+            a.mmax[e] = o.mmax[e]; a.am[e] = o.am[e];
+        }
+    }
+}
+
+__device__ __forceinline__ Pool4 pool4_shfl_xor(const Pool4& a, int mask) {
+    Pool4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o.msum[e] = __shfl_xor(a.msum[e], mask, 64); o.usum[e] = __shfl_xor(a.usum[e], mask, 64);
+        o.mmax[e] = __shfl_xor(a.mmax[e], mask, 64); o.umax[e] = __shfl_xor(a.umax[e], mask, 64);
+        o.am[e] = __shfl_xor(a.am[e], mask, 64);     o.au[e] = __shfl_xor(a.au[e], mask, 64);
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void pool4_partial_v4_kernel(const float* __restrict__ pf, const float* __restrict__ valid,
+                                                                int N, int C, int nsplit, int npb,
+                                                                PoolPart* __restrict__ part, float* __restrict__ cnt_part) {
+    __shared__ Pool4 s_p[3][16];
+    __shared__ float s_cnt[4];
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rsub = lane >> 4, c = blockIdx.x * 64 + (lane & 15) * 4;
+    const int n0 = sp * npb, n1 = min(N, n0 + npb);
+    Pool4 a;
+    a.msum = a.usum = f32x4{0.f, 0.f, 0.f, 0.f};
+    a.mmax = a.umax = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.am[e] = a.au[e] = -1;
+    float cnt = 0.f;
+    const float* base = pf + (size_t)b * N * C + c;
+    const float* vp = valid + (size_t)b * N;
+    constexpr int U = 4;                                   // 4 independent 16-B loads per lane in flight
+    for (int n = n0 + wave * 4 + rsub; n < n1; n += 16 * U) {
+        f32x4 v[U];
+        float ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int nn = n + 16 * u;
+            if (nn < n1) { v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)nn * C); ok[u] = vp[nn]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int nn = n + 16 * u;
+            if (nn < n1) {
+                a.usum += v[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[u][e] > a.umax[e] || a.au[e] < 0) { a.umax[e] = v[u][e]; a.au[e] = nn; }
+                if (ok[u] != 0.f) {
+                    a.msum += v[u];
+                    cnt += 1.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (v[u][e] > a.mmax[e] || a.am[e] < 0) { a.mmax[e] = v[u][e]; a.am[e] = nn; }
+                }
+            }
+        }
+    }
+    // wavefront shuffle tree over the wave's 4 row groups
+    pool4_merge(a, pool4_shfl_xor(a, 16));
+    pool4_merge(a, pool4_shfl_xor(a, 32));
+    cnt += __shfl_xor(cnt, 16, 64);
+    cnt += __shfl_xor(cnt, 32, 64);
+    // LDS tree over the 4 waves
+    if (wave > 0 && lane < 16) s_p[wave - 1][lane] = a;
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+        pool4_merge(a, s_p[0][lane]);
+        pool4_merge(a, s_p[1][lane]);
+        pool4_merge(a, s_p[2][lane]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            part[((size_t)b * nsplit + sp) * C + c + e] = PoolPart{a.msum[e], a.usum[e], a.mmax[e], a.umax[e], a.am[e], a.au[e]};
+        if (blockIdx.x == 0 && lane == 0) cnt_part[b * nsplit + sp] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
 }
 
 __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __restrict__ part,
@@ -203,10 +302,13 @@ __global__ __launch_bounds__(256) void pool4_bwd_bias_kernel(const float* __rest
     }
 }
 
+bool pool_v4(const float* pf, int C) { return C % 64 == 0 && ((uintptr_t)pf % 16) == 0; }
+
 int pool_nsplit(int B, int N, int C) {
-    const int cb = wf3d_cdiv(C, 256);
-    int ns = 2048 / (B * cb > 0 ? B * cb : 1);
-    const int cap = wf3d_cdiv(N, 32);
+    // v4 kernel: C/64 workgroups per (cloud, split), >= 64 rows per wave; fallback: C/256 per (cloud, split)
+    const int cb = C % 64 == 0 ? C / 64 : wf3d_cdiv(C, 256);
+    int ns = (C % 64 == 0 ? 4096 : 2048) / (B * cb > 0 ? B * cb : 1);
+    const int cap = wf3d_cdiv(N, C % 64 == 0 ? 256 : 32);
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     return ns;
@@ -245,7 +347,10 @@ extern "C" int wf3d_pool4_fwd(const float* pf, const float* valid, int B, int N,
     size_t off = ((size_t)B * ns * C * sizeof(PoolPart) + 255) & ~(size_t)255;
     float* cnt_part = (float*)((char*)ws + off);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pool4_partial_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, st, pf, valid, N, C, ns, npb, part, cnt_part);
+    if (pool_v4(pf, C))
+        hipLaunchKernelGGL(pool4_partial_v4_kernel, dim3(C / 64, ns, B), dim3(256), 0, st, pf, valid, N, C, ns, npb, part, cnt_part);
+    else
+        hipLaunchKernelGGL(pool4_partial_kernel, dim3(wf3d_cdiv(C, 256), ns, B), dim3(256), 0, st, pf, valid, N, C, ns, npb, part, cnt_part);
     WF3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(pool4_final_kernel, dim3(wf3d_cdiv(C, 256), B), dim3(256), 0, st, part, cnt_part, N, C, ns, ldo, nvalid,
                        mmax, mavg, umean, umax, arg_m, arg_u, cnt);

@@ -69,12 +69,18 @@ def _stage_of(name):
 class GradReducer:
     """Bucketed, overlapped gradient averaging.
 
-    usage:   red = GradReducer(model);  loss.backward();  red.finish()
+    usage:   red = GradReducer(model);  loss.backward();  red.finish()      (one backward per finish)
     Buckets follow backward order; a bucket's all-reduce starts from a
-    post-accumulate-grad hook when its last parameter's gradient lands, on the
-    communication stream of the process group (async_op), and `finish()` waits
-    and scatters the averaged values back into `.grad`.
-    """
+    post-accumulate-grad hook when the last of the parameters that are EXPECTED to receive a
+    gradient has received its own, on the communication stream of the process group (async_op),
+    and `finish()` waits and scatters the averaged values back into `.grad`.
+
+    Expected = every parameter that has ever received a gradient (learned; parameters that never do —
+    EdgePredictor.spatial_proj, SURVEY §9 Q2 — must not hold a bucket back).  A gradient that lands
+    AFTER its bucket was launched (a parameter receiving its first gradient, or a second backward before
+    finish()) marks the bucket stale: finish() then waits for the in-flight reduce and reduces that
+    bucket again from the final .grad values, so nothing stale is ever written back.
+    `exposed_ms()` = time the compute stream spent inside finish() (un-overlapped communication)."""
 
     def __init__(self, module, bucket_mb=48.0, group=None, average=True):
         self.module, self.group, self.average = module, group, average
@@ -82,8 +88,8 @@ class GradReducer:
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self._buckets = None
         self._hooks = []
-        self._pending = []
-        self._seen = set()
+        self._ever = set()               # parameters that have received a gradient at least once
+        self._events = []
         self._build()
 
     def _build(self):
@@ -109,8 +115,8 @@ class GradReducer:
         self._owner = {}
         for bi, ps in enumerate(buckets):
             flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
-            self._buckets.append({"params": ps, "flat": flat, "ready": 0, "work": None, "launched": False,
-                                  "expect": len(ps)})
+            self._buckets.append({"params": ps, "flat": flat, "got": set(), "work": None, "launched": False,
+                                  "stale": False, "views": None})
             for p in ps:
                 self._owner[p] = bi
         self._n_params = len(named)
@@ -118,18 +124,19 @@ class GradReducer:
             for _, p in named:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _maybe_rebuild(self):
-        n = sum(1 for p in self.module.parameters() if p.requires_grad)
-        if n != self._n_params:                 # a lazy parameter appeared
-            self._build()
+    def _expected(self, b):
+        exp = [p for p in b["params"] if p in self._ever]
+        return exp if exp else b["params"]          # first step: nothing learned yet -> wait for everything
 
     def _on_grad(self, p):
         bi = self._owner.get(p)
         if bi is None:
             return
         b = self._buckets[bi]
-        b["ready"] += 1
-        if b["ready"] >= b["expect"] and not b["launched"]:
+        if b["launched"] or p in b["got"]:
+            b["stale"] = True                       # a gradient after the launch / a second backward: redo in finish()
+        b["got"].add(p)
+        if not b["launched"] and all(q in b["got"] for q in self._expected(b)):
             self._launch(b)
 
     def _launch(self, b):
@@ -150,8 +157,20 @@ class GradReducer:
         parameters without a gradient this step) and write averages into .grad."""
         if self.world == 1:
             return
-        self._maybe_rebuild()
+        timed = torch.cuda.is_available() and self._buckets and self._buckets[0]["flat"].is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        n = sum(1 for p in self.module.parameters() if p.requires_grad)
+        if n != self._n_params:                     # a lazy parameter appeared: drain, re-bucket, reduce everything now
+            for b in self._buckets:
+                if b["work"] is not None:
+                    b["work"].wait()
+            self._build()
         for b in self._buckets:
+            if b["launched"] and b["stale"]:
+                b["work"].wait()                    # the early reduce carried stale values: do it again
+                b["launched"] = False
             if not b["launched"]:
                 self._launch(b)
         scale = 1.0 / self.world if self.average else 1.0
@@ -163,10 +182,22 @@ class GradReducer:
             src = [v for p, v in zip(b["params"], b["views"]) if p.grad is not None]
             if dst:
                 torch._foreach_copy_(dst, src)
-            # parameters that never receive a gradient (EdgePredictor.spatial_proj)
-            # must not hold the bucket back next step
-            b["expect"] = max(1, len(dst))
-            b["ready"], b["work"], b["launched"] = 0, None, False
+            self._ever.update(p for p in b["params"] if p.grad is not None)
+            b["got"], b["work"], b["launched"], b["stale"] = set(), None, False, False
+        if timed:
+            e1.record()
+            self._events.append((e0, e1))
+
+    def exposed_ms(self, reset=True):
+        """Per-step times (ms) the compute stream spent in finish(): all-reduce not hidden under backward, plus the
+        scale / copy-back kernels.  Synchronises."""
+        if not self._events:
+            return []
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._events]
+        if reset:
+            self._events = []
+        return out
 
     def bucket_summary(self):
         return [(len(b["params"]), b["flat"].numel() * b["flat"].element_size()) for b in self._buckets]
