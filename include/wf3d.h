@@ -289,12 +289,13 @@ int wf3d_pool4_bwd_sx8(const float* valid, const float* cnt, const int32_t* arg_
 /* ------------------------------------------------------------------------
  * Vertex head tail (VertexPredictor.py:118-127): existence = sigmoid(o[:,:,3]),
  * actual_vertex_counts = sum(existence > 0.5) (int64), o = final_layer output
- * [B, V, vertex_dim >= 4]; backward: d_o = d_o_in (grad that reached o through the
- * vertices view, may be NULL) with dexist*p*(1-p) added into channel 3.
+ * [B, V, vertex_dim >= 4]; backward: d_o[.., k] = d_o_in[.., k] for k < in_dim (d_o_in [B, V, in_dim] contiguous:
+ * in_dim = 3 is the gradient of the `vertices` view o[:, :, :3] itself, in_dim = vertex_dim a gradient of o; may be
+ * NULL), 0 elsewhere, with dexist*p*(1-p) added into channel 3.
  * ------------------------------------------------------------------------ */
 int wf3d_vertex_finalize_fwd(const float* o, int B, int V, int vertex_dim, float* exist, int64_t* counts,
                              void* stream);
-int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const float* d_o_in, int B, int V,
+int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const float* d_o_in, int in_dim, int B, int V,
                              int vertex_dim, float* d_o, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -339,10 +340,9 @@ int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, c
                        int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample, int Rv,
                        int H, float* dPa, float* dPb, float* dcv, void* stream);
 
-/* probs[s, e - eoff[s]] = sigmoid(logit[e]) into the zero-initialised padded
- * [B, max_e] output (PointCloudToWireframe.py:103-112), and its backward. */
-int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, const int32_t* esample, int Re, int max_e,
-                       float* probs, void* stream);
+/* probs[s, j] = sigmoid(logit[eoff[s] + j]) for j < E_s and exactly 0.0 for the padding j >= E_s: the whole padded
+ * [B, max_e] output of PointCloudToWireframe.py:103-112 in one pass (no zero-fill first), and its backward. */
+int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, int B, int max_e, float* probs, void* stream);
 int wf3d_edge_prob_bwd(const float* probs, const float* dprobs, const int32_t* eoff, const int32_t* esample, int Re,
                        int max_e, float* dlogit, void* stream);
 

@@ -238,14 +238,14 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
         dcv[r * 3 + threadIdx.x] = (rc[threadIdx.x] + rc[3 + threadIdx.x]) + (rc[6 + threadIdx.x] + rc[9 + threadIdx.x]);
 }
 
-// ---- sigmoid + scatter into the zero-padded [B, max_E] output ---------------------
+// ---- sigmoid into the padded [B, max_E] output; the padding (exactly 0.0) is written here too ----
 __global__ __launch_bounds__(256) void edge_prob_fwd_kernel(const float* __restrict__ logit, const int32_t* __restrict__ eoff,
-                                                             const int32_t* __restrict__ esample, int Re, int max_e,
-                                                             float* __restrict__ probs) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Re) return;
-    const int s = esample[e];
-    probs[(size_t)s * max_e + (e - eoff[s])] = 1.0f / (1.0f + expf(-logit[e]));
+                                                             int B, int max_e, float* __restrict__ probs) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * max_e) return;
+    const int s = (int)(idx / max_e), j = (int)(idx - (long)s * max_e);
+    const int e0 = eoff[s], ne = eoff[s + 1] - e0;
+    probs[idx] = j < ne ? 1.0f / (1.0f + expf(-logit[e0 + j])) : 0.0f;
 }
 __global__ __launch_bounds__(256) void edge_prob_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dprobs,
                                                              const int32_t* __restrict__ eoff,
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void vertex_finalize_fwd_kernel(const float* _
     if (threadIdx.x == 0) counts[b] = cnt;
 }
 __global__ __launch_bounds__(256) void vertex_finalize_bwd_kernel(const float* __restrict__ exist, const float* __restrict__ dexist,
-                                                                   const float* __restrict__ d_o_in, int BV, int vd,
+                                                                   const float* __restrict__ d_o_in, int in_dim, int BV, int vd,
                                                                    float* __restrict__ d_o) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= BV * vd) return;
     const int k = idx % vd, bv = idx / vd;
-    float g = d_o_in ? d_o_in[idx] : 0.f;
+    float g = (d_o_in && k < in_dim) ? d_o_in[bv * in_dim + k] : 0.f;
     if (k == 3 && dexist) { const float p = exist[bv]; g += dexist[bv] * p * (1.0f - p); }
     d_o[idx] = g;
 }
@@ -379,13 +379,12 @@ extern "C" int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const f
     return WF3D_OK;
 }
 
-extern "C" int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, const int32_t* esample, int Re, int max_e,
-                                  float* probs, void* stream) {
-    WF3D_CHECK(Re >= 0 && max_e >= 0, WF3D_ERR_ARG, "wf3d_edge_prob_fwd: bad dims");
-    if (Re == 0) return WF3D_OK;
-    WF3D_CHECK(logit && eoff && esample && probs, WF3D_ERR_ARG, "wf3d_edge_prob_fwd: null pointer");
-    hipLaunchKernelGGL(edge_prob_fwd_kernel, dim3(wf3d_cdiv(Re, 256)), dim3(256), 0, (hipStream_t)stream, logit, eoff,
-                       esample, Re, max_e, probs);
+extern "C" int wf3d_edge_prob_fwd(const float* logit, const int32_t* eoff, int B, int max_e, float* probs, void* stream) {
+    WF3D_CHECK(B >= 0 && max_e >= 0, WF3D_ERR_ARG, "wf3d_edge_prob_fwd: bad dims");
+    if (B == 0 || max_e == 0) return WF3D_OK;
+    WF3D_CHECK(logit && eoff && probs, WF3D_ERR_ARG, "wf3d_edge_prob_fwd: null pointer");
+    hipLaunchKernelGGL(edge_prob_fwd_kernel, dim3(wf3d_cdiv((long)B * max_e, 256)), dim3(256), 0, (hipStream_t)stream, logit, eoff,
+                       B, max_e, probs);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
@@ -411,13 +410,13 @@ extern "C" int wf3d_vertex_finalize_fwd(const float* o, int B, int V, int vertex
     return WF3D_OK;
 }
 
-extern "C" int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const float* d_o_in, int B, int V,
+extern "C" int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const float* d_o_in, int in_dim, int B, int V,
                                         int vertex_dim, float* d_o, void* stream) {
-    WF3D_CHECK(B >= 0 && V > 0 && vertex_dim >= 4, WF3D_ERR_ARG, "wf3d_vertex_finalize_bwd: bad dims");
+    WF3D_CHECK(B >= 0 && V > 0 && vertex_dim >= 4 && in_dim >= 1 && in_dim <= vertex_dim, WF3D_ERR_ARG, "wf3d_vertex_finalize_bwd: bad dims");
     if (B == 0) return WF3D_OK;
     WF3D_CHECK(exist && d_o, WF3D_ERR_ARG, "wf3d_vertex_finalize_bwd: null pointer");
     hipLaunchKernelGGL(vertex_finalize_bwd_kernel, dim3(wf3d_cdiv((long)B * V * vertex_dim, 256)), dim3(256), 0,
-                       (hipStream_t)stream, exist, dexist, d_o_in, B * V, vertex_dim, d_o);
+                       (hipStream_t)stream, exist, dexist, d_o_in, in_dim, B * V, vertex_dim, d_o);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

@@ -409,6 +409,13 @@ SplitPlan plan_split(int M, int N, int K, int bm, int bn) {
 }
 
 inline bool small_m(int M) { return M <= 64; }
+// A few thousand rows (the edge head's per-vertex Linears, M = sum of vertex counts): 128 x 128 tiles give fewer than
+// one workgroup per CU and then need split-K slabs plus a reduce launch; 64 x 64 tiles (one MFMA tile per wave) fill
+// the chip directly.  Only when the reduction is short enough that the halved operand reuse does not matter.
+inline bool mid_tile(int M, int N, int K) {
+    const long t128 = (long)wf3d_cdiv(M, 128) * wf3d_cdiv(N, 128), t64 = (long)wf3d_cdiv(M, 64) * wf3d_cdiv(N, 64);
+    return M > 64 && t128 < 192 && t64 >= 128 && K <= 2048;
+}
 
 template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int ACT, bool PRO>
 void launch(const GemmParams& p, hipStream_t st) {
@@ -417,9 +424,10 @@ void launch(const GemmParams& p, hipStream_t st) {
 }
 
 template <bool AKC, bool BKC, int ACT, bool PRO>
-void launch_tile(const GemmParams& p, bool small, hipStream_t st) {
-    if (small) launch<1, 4, 1, 1, AKC, BKC, ACT, PRO>(p, st);
-    else       launch<2, 2, 2, 2, AKC, BKC, ACT, PRO>(p, st);
+void launch_tile(const GemmParams& p, int kind, hipStream_t st) {       // kind: 1 = 32 x 128, 2 = 64 x 64, 0 = 128 x 128
+    if (kind == 1)      launch<1, 4, 1, 1, AKC, BKC, ACT, PRO>(p, st);
+    else if (kind == 2) launch<2, 2, 1, 1, AKC, BKC, ACT, PRO>(p, st);
+    else                launch<2, 2, 2, 2, AKC, BKC, ACT, PRO>(p, st);
 }
 
 }  // namespace
@@ -427,7 +435,8 @@ void launch_tile(const GemmParams& p, bool small, hipStream_t st) {
 extern "C" size_t wf3d_gemm_ws_bytes(int M, int N, int K, int layout) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const bool small = layout != WF3D_TN && small_m(M);
-    SplitPlan s = plan_split(M, N, K, small ? 32 : 128, 128);
+    const bool mid = layout != WF3D_TN && !small && mid_tile(M, N, K);
+    SplitPlan s = plan_split(M, N, K, small ? 32 : (mid ? 64 : 128), mid ? 64 : 128);
     return s.ksplit > 1 ? (size_t)s.ksplit * M * N * sizeof(float) : 0;
 }
 
@@ -467,7 +476,9 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     p.vecP = !p.has_affine || (((uintptr_t)d->pro_gamma % 16 == 0) && ((uintptr_t)d->pro_beta % 16 == 0));
 
     const bool small = d->layout != WF3D_TN && small_m(d->M);
-    const int bm = small ? 32 : 128, bn = 128;
+    const bool mid = d->layout != WF3D_TN && !small && mid_tile(d->M, d->N, d->K);
+    const int kind = small ? 1 : (mid ? 2 : 0);
+    const int bm = small ? 32 : (mid ? 64 : 128), bn = mid ? 64 : 128;
     p.nbm = wf3d_cdiv(d->M, bm);
     p.nbn = wf3d_cdiv(d->N, bn);
     SplitPlan s = plan_split(d->M, d->N, d->K, bm, bn);
@@ -480,12 +491,12 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     const int act = d->pro_enable ? d->pro_act : 0;
     const bool pro = d->pro_enable != 0;
     if (d->layout == WF3D_NT) {
-        if (!pro)                         launch_tile<true, true, 0, false>(p, small, st);
-        else if (act == WF3D_ACT_RELU)    launch_tile<true, true, WF3D_ACT_RELU, true>(p, small, st);
-        else if (act == WF3D_ACT_GELU)    launch_tile<true, true, WF3D_ACT_GELU, true>(p, small, st);
-        else                              launch_tile<true, true, WF3D_ACT_NONE, true>(p, small, st);
+        if (!pro)                         launch_tile<true, true, 0, false>(p, kind, st);
+        else if (act == WF3D_ACT_RELU)    launch_tile<true, true, WF3D_ACT_RELU, true>(p, kind, st);
+        else if (act == WF3D_ACT_GELU)    launch_tile<true, true, WF3D_ACT_GELU, true>(p, kind, st);
+        else                              launch_tile<true, true, WF3D_ACT_NONE, true>(p, kind, st);
     } else if (d->layout == WF3D_NN) {
-        launch_tile<true, false, 0, false>(p, small, st);
+        launch_tile<true, false, 0, false>(p, kind, st);
     } else {
         if (!pro)                         launch<2, 2, 2, 2, false, false, 0, false>(p, st);
         else if (act == WF3D_ACT_RELU)    launch<2, 2, 2, 2, false, false, WF3D_ACT_RELU, true>(p, st);

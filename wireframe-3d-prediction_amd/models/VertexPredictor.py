@@ -50,7 +50,7 @@ class VertexPredictor(nn.Module):
             self.ensure_point_pool_proj(upooled.shape[1], upooled.device)
         o, exist, counts = VertexFn.apply(global_features, upooled, self.max_vertices,
                                           self.vertex_dim, *self._param_list(with_pool))
-        return {"vertices": o[:, :, :3],                 # non-contiguous view, like the reference (:122)
+        return {"vertices": o,                            # non-contiguous [B, V, 3] view of the [B, V, 4] output (:122)
                 "existence_probabilities": exist,
                 "actual_vertex_counts": counts}
 

@@ -125,7 +125,7 @@ SIGNATURES = {
     "wf3d_pool4_bwd_sx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "wf3d_vertex_finalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_vertex_finalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_edge_gather_verts": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p,
                                        c_void_p]),
     "wf3d_edge_scatter_dverts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -140,7 +140,7 @@ SIGNATURES = {
                                    c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf3d_edge_pair_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "wf3d_edge_prob_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_edge_prob_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_loss_cost_matrix": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                       c_int, c_void_p, c_void_p]),
     "wf3d_loss_assign": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

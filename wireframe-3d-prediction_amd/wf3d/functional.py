@@ -262,7 +262,7 @@ class FusionFn(torch.autograd.Function):
 # Vertex head
 # ===========================================================================
 class VertexFn(torch.autograd.Function):
-    """(g[B,C], upooled[B,2C] = [mean | max] or None, params) -> (o[B,V,vd], exist[B,V], counts[B] int64)
+    """(g[B,C], upooled[B,2C] = [mean | max] or None, params) -> (vertices[B,V,3] (view of o[B,V,vd]), exist[B,V], counts[B] int64)
 
     params = [W1,b1,g1,be1, W2,b2,g2,be2, W3,b3,g3,be3, W4,b4,g4,be4, Wf,bf, Wr1,br1, Wr2,br2, (Wpp,bpp)]
 
@@ -312,7 +312,9 @@ class VertexFn(torch.autograd.Function):
         ctx.saved = (upooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d)
         ctx.save_for_backward(exist)
         ctx.mark_non_differentiable(counts)
-        return o.view(B, V, vd), exist, counts
+        # `vertices` = the first three channels, a non-contiguous view as in the reference (VertexPredictor.py:122); handing
+        # the view out directly spares autograd's slice backward (a zero-fill and a strided copy per step)
+        return o.view(B, V, vd)[:, :, :3], exist, counts
 
     @staticmethod
     def backward(ctx, do3, dexist, _dcounts):
@@ -500,7 +502,7 @@ class EdgeFn(torch.autograd.Function):
         # LN/GELU backward of the first edge layer; the same pass yields the gradient of its distance-weight column
         dpre, G[14], G[15], wsum = ops.ln_act_bwd_wsum(dh1, pre, delta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], inplace=True)
         # split first layer backward
-        dW0 = torch.zeros_like(M0w)
+        dW0 = torch.empty_like(M0w)           # every column is written below: Wa | Wb | Wc | Wd | w_delta
         dW0[:, 2 * H + 6].copy_(wsum)
         dPa, dPb, dcv = ops.edge_pair_bwd(dpre, delta, cv, M0w, meta)
         G[13] = ops.colsum(dPa)

@@ -345,12 +345,14 @@ def vertex_finalize_fwd(o, V, vd):
 
 
 def vertex_finalize_bwd(exist, dexist, d_o_in, B, V, vd):
+    """d_o_in: gradient of o [B, V, vd] or of the `vertices` view o[:, :, :3] ([B, V, 3]), contiguous, or None."""
     _need_cuda(exist, dexist, d_o_in)
     for t in (dexist, d_o_in):
         if t is not None and not t.is_contiguous():
             raise RuntimeError("wf3d.vertex_finalize_bwd: contiguous cotangents required")
+    in_dim = d_o_in.shape[-1] if d_o_in is not None else vd
     d_o = torch.empty(B, V * vd, dtype=torch.float32, device=exist.device)
-    check(_lib.load().wf3d_vertex_finalize_bwd(_p(exist), _p(dexist), _p(d_o_in), B, V, vd, _p(d_o), _stream()),
+    check(_lib.load().wf3d_vertex_finalize_bwd(_p(exist), _p(dexist), _p(d_o_in), in_dim, B, V, vd, _p(d_o), _stream()),
           "vertex_finalize_bwd")
     return d_o
 
@@ -425,12 +427,21 @@ def attn_bwd(qkv, dctx, ctx, lse, meta, E, heads, drop_p=0.0, seed=0):
     return dqkv
 
 
+_wdelta_cache = [None, -1, None]       # (weight tensor, its version, contiguous distance column)
+
+
 def _wdelta(W0, H):
     """Distance column of edge_mlp.0.weight, gathered once into a contiguous vector (a strided
-    per-lane gather of it inside the pair kernels costs 512 uncoalesced loads per edge row)."""
+    per-lane gather of it inside the pair kernels costs 512 uncoalesced loads per edge row).
+    Forward and backward of one step see the same weight version and share the copy."""
     if tuple(W0.shape) != (H, 2 * H + 7):
         raise RuntimeError("wf3d: edge_mlp.0.weight must be [H, 2H+7]")
-    return W0[:, 2 * H + 6].contiguous(), 1
+    c = _wdelta_cache
+    if c[0] is W0 and c[1] == W0._version:
+        return c[2], 1
+    col = W0.detach()[:, 2 * H + 6].contiguous()
+    c[0], c[1], c[2] = W0, W0._version, col
+    return col, 1
 
 
 def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None):
@@ -474,9 +485,8 @@ def edge_pair_bwd(dpre, delta, cv, W0, meta):
 
 def edge_prob_fwd(logit, meta):
     _need_cuda(logit)
-    probs = torch.zeros(meta.B, meta.max_e, dtype=torch.float32, device=logit.device)   # padding is exactly 0.0
-    check(_lib.load().wf3d_edge_prob_fwd(_p(logit), _p(meta.eoff), _p(meta.esample), meta.Re, meta.max_e, _p(probs),
-                                         _stream()), "edge_prob_fwd")
+    probs = torch.empty(meta.B, meta.max_e, dtype=torch.float32, device=logit.device)   # the kernel writes the 0.0 padding too
+    check(_lib.load().wf3d_edge_prob_fwd(_p(logit), _p(meta.eoff), meta.B, meta.max_e, _p(probs), _stream()), "edge_prob_fwd")
     return probs
 
 
