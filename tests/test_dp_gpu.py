@@ -2,7 +2,12 @@
 box through the gloo backend — RCCL refuses two ranks on one device) each run half of a
 batch through PointCloudToWireframe on the HIP path and average gradients with
 wf3d.dist.GradReducer; the result must equal the single-process gradient of the whole
-batch (no cross-sample statistic anywhere in the path)."""
+batch (no cross-sample statistic anywhere in the path).
+
+Second test: the same with RAGGED vertex counts and the real WireframeLoss, whose normalisers are
+batch-wide (matched-vertex count, B x common edge width — SURVEY.md §8e caveat, reference
+losses/WireframeLoss.py:82-86,276-281): `WireframeLoss.set_data_parallel()` exchanges them, and the
+mean over ranks of the local losses / gradients must equal the single-process loss / gradient."""
 import os
 import socket
 
@@ -92,6 +97,95 @@ def test_two_rank_gradients_equal_single_process_batch():
     x, counts, cot = _inputs(B, N, V)
     # mean over the two shards of (shard loss / shard size) == whole-batch loss / B for equal shards
     _run(model, x, counts, cot, dev, 1.0 / B)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert n not in grads
+            continue
+        a, b = torch.from_numpy(grads[n]).double(), p.grad.detach().cpu().double()
+        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
+    assert worst < 2e-3, worst
+
+
+# ---------------------------------------------------------------------------
+# ragged counts + the real loss (batch-wide normalisers all-reduced)
+# ---------------------------------------------------------------------------
+def _loss_case(B, N, V):
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(B, N, 8, generator=g)
+    x[2, N // 3:] = 0
+    counts = torch.tensor([V, 3, V - 2, 2][:B])                  # rank 0: {V, 3}, rank 1: {V-2, 2}: widths and match counts differ
+    E = V * (V - 1) // 2
+    tv = torch.randn(B, V, 3, generator=g)
+    te = (torch.arange(V)[None, :] < counts[:, None]).float()
+    tl = torch.zeros(B, E)
+    for b in range(B):
+        eb = int(counts[b]) * (int(counts[b]) - 1) // 2
+        tl[b, :eb] = (torch.rand(eb, generator=g) < 0.3).float()  # labels beyond a sample's own edges stay 0 (as train.py builds them)
+    return x, counts, {"vertices": tv, "vertex_existence": te, "edge_labels": tl, "vertex_counts": counts}
+
+
+def _loss_step(model, crit, x, counts, tg, dev, sl):
+    out = model(x[sl].to(dev), counts[sl].to(dev))
+    res = crit(out, {k: v[sl].to(dev) for k, v in tg.items()})
+    res["total_loss"].backward()
+    return res
+
+
+def _worker_loss(rank, world, port, B, N, V, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), WF3D_DIST_BACKEND="gloo")
+    from wf3d import dist as wd
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    from losses.WireframeLoss import WireframeLoss
+    r, w, dev = wd.init_from_env("cuda")
+    torch.manual_seed(77)
+    model = PointCloudToWireframe(8, V).to(dev).set_dropout(0.0)
+    model.vertex_predictor.ensure_point_pool_proj(1024, dev)
+    wd.sync_parameters(model)
+    model.train()
+    crit = WireframeLoss(vertex_weight=3.0, edge_weight=1.0, existence_weight=1.5).set_data_parallel()
+    red = wd.GradReducer(model)
+    x, counts, tg = _loss_case(B, N, V)
+    lo, hi = wd.shard_batch(B, rank, world)
+    res = _loss_step(model, crit, x, counts, tg, dev, slice(lo, hi))
+    red.finish()
+    tot = res["total_loss"].detach().clone()
+    torch.distributed.all_reduce(tot)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put({n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None})
+        q.put({n: p.detach().cpu().numpy() for n, p in model.named_parameters()})
+        q.put(float(tot) / world)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_real_loss_with_ragged_counts_equals_single_process():
+    B, N, V = 4, 96, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_loss, args=(r, 2, port, B, N, V, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, params, mean_total = q.get(timeout=300), q.get(timeout=300), q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    from losses.WireframeLoss import WireframeLoss
+    dev = torch.device("cuda:0")
+    model = PointCloudToWireframe(8, V).to(dev).set_dropout(0.0)
+    model.vertex_predictor.ensure_point_pool_proj(1024, dev)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(params[n]))
+    model.train()
+    x, counts, tg = _loss_case(B, N, V)
+    crit = WireframeLoss(vertex_weight=3.0, edge_weight=1.0, existence_weight=1.5)
+    res = _loss_step(model, crit, x, counts, tg, dev, slice(0, B))
+    assert abs(float(res["total_loss"]) - mean_total) < 1e-5 * max(1.0, abs(mean_total)), (float(res["total_loss"]), mean_total)
     worst = 0.0
     for n, p in model.named_parameters():
         if p.grad is None:

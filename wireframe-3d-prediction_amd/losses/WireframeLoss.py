@@ -1,11 +1,23 @@
 """Drop-in `losses.WireframeLoss.WireframeLoss` (reference losses/WireframeLoss.py:6-283) — row f-1,
 the caller of the hot path's backward.
 
-Same constructor, same `forward(predictions, targets) -> dict` with the same four keys.  The
-Hungarian assignment is still scipy's `linear_sum_assignment` on the host (as in the reference,
-:236), but all B cost matrices come from ONE kernel and ONE device->host copy (the reference does a
-`.cpu().numpy()` sync per sample), and SmoothL1 / BCE / BCE plus their gradients w.r.t. the model
-outputs are one more kernel; `total_loss.backward()` hands those gradients to the model."""
+Same constructor, same `forward(predictions, targets) -> dict` with the same four keys.  Default
+(`assignment="device"`): the B Hungarian cost matrices, the assignment itself (Jonker-Volgenant on the
+device, csrc/loss.hip), SmoothL1 / BCE / BCE and their gradients w.r.t. the model outputs are three
+kernel launches with no host synchronisation; `total_loss.backward()` hands those gradients to the model.
+`assignment="scipy"` keeps the reference's host solver (`linear_sum_assignment`, :236) behind ONE
+device->host copy for the batch (the reference syncs per sample).
+
+Differences to know about:
+  * target counts larger than min(max_vertices, targets['vertices'].shape[1]) are CLAMPED on the device path
+    (the reference's inf-padded cost matrix makes scipy raise there; raising would need a host sync); the
+    scipy path raises like the reference.
+  * exactly tied assignment costs: the device solver works on the same padded square problem in the same row
+    order as scipy and reproduced its matches on every tested tie, but ties are not pinned by any fixture.
+  * `set_data_parallel()`: with one process per GPU each rank sees a slice of the batch, but the reference's
+    normalisers are batch-wide (matched-vertex count, :276-281; B x common edge width, :82-86).  When enabled,
+    the three normalisers are exchanged (one tiny all-reduce) and each term is rescaled so that the MEAN over
+    ranks of the local losses / gradients equals the single-process loss / gradient of the whole batch."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -18,7 +30,7 @@ class _LossDevFn(torch.autograd.Function):
     """Fully asynchronous variant: cost matrices, assignment, loss terms and gradients all on the device."""
 
     @staticmethod
-    def forward(ctx, verts, exist, edge, tverts, texist, tlabel, counts, weights):
+    def forward(ctx, verts, exist, edge, tverts, texist, tlabel, counts, weights, scales=None):
         exist_c = exist.contiguous()
         cost = ops.loss_cost_matrix(verts, exist_c, tverts, counts)
         # the square problem, rows in prediction order like scipy: L1 costs have exact ties (2 of 32 random samples
@@ -26,6 +38,10 @@ class _LossDevFn(torch.autograd.Function):
         col4row = ops.loss_assign(cost)
         losses, dv, de, dd = ops.loss_terms_assigned(verts, exist_c, edge.contiguous(), tverts, texist, tlabel,
                                                      col4row, counts, weights)
+        if scales is not None:       # data-parallel renormalisation: (vertex, existence, edge) factors, device scalars
+            w = torch.tensor(weights, dtype=torch.float32, device=losses.device)
+            losses = torch.cat([losses[:3], (losses[:3] * w * scales).sum().reshape(1)])
+            dv, de, dd = dv * scales[0], de * scales[1], dd * scales[2]
         ctx.save_for_backward(dv, de, dd)
         ctx.mark_non_differentiable(losses)
         return losses[3].clone(), losses
@@ -33,7 +49,7 @@ class _LossDevFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_losses):
         dv, de, dd = ctx.saved_tensors
-        return (dv * g_total, de * g_total, dd * g_total, None, None, None, None, None)
+        return (dv * g_total, de * g_total, dd * g_total, None, None, None, None, None, None)
 
 
 class _LossFn(torch.autograd.Function):
@@ -64,6 +80,32 @@ class WireframeLoss(nn.Module):
         self.existence_weight = existence_weight
         self.smooth_l1_loss = nn.SmoothL1Loss()      # kept for attribute parity; not called
         self.bce_loss = nn.BCELoss()
+        self._dp = (False, None)
+
+    def set_data_parallel(self, enabled=True, group=None):
+        """One process per GPU, batch sharded over ranks: rescale the three terms to the batch-wide normalisers
+        (module docstring).  No effect in a single process."""
+        self._dp = (bool(enabled), group)
+        return self
+
+    def _dp_scales(self, counts, B, V, e_pred, e_tgt, dev):
+        """(vertex, existence, edge) factors s with  mean_over_ranks(s * local term) == whole-batch term; None when not DP.
+        One all-reduce of a [world, 3] tensor, nothing read back to the host."""
+        import torch.distributed as dist
+        enabled, group = self._dp
+        if not enabled or not (dist.is_available() and dist.is_initialized()):
+            return None
+        W = dist.get_world_size(group)
+        if W == 1:
+            return None
+        r = dist.get_rank(group)
+        mine = torch.stack([counts.clamp(max=V).sum().to(torch.float32),
+                            torch.tensor(float(B), device=dev), torch.tensor(float(min(e_pred, e_tgt)), device=dev)])
+        table = torch.zeros(W, 3, dtype=torch.float32, device=dev)
+        table[r] = mine
+        dist.all_reduce(table, group=group)
+        n_g, b_g, w_g = table[:, 0].sum().clamp_min(1.0), table[:, 1].sum(), table[:, 2].max().clamp_min(1.0)
+        return torch.stack([W * mine[0] / n_g, W * mine[1] / b_g, W * mine[1] * mine[2] / (b_g * w_g)])
 
     def _hungarian_matching(self, predictions, targets):
         """list of (pred_indices, target_indices) numpy arrays per sample (reference :106-237)."""
@@ -88,13 +130,23 @@ class WireframeLoss(nn.Module):
         pe = predictions["existence_probabilities"]
         pp = predictions["edge_probs"]
         dev = pv.device
+        B, V = pv.shape[0], pv.shape[1]
+        if tuple(pe.shape) != (B, V):
+            raise ValueError(f"existence_probabilities must be [B, V] = {(B, V)}, got {tuple(pe.shape)}")
+        if tuple(targets["vertex_existence"].shape) != (B, V):
+            raise ValueError(f"targets['vertex_existence'] must be [B, V] = {(B, V)}, got {tuple(targets['vertex_existence'].shape)}")
+        if targets["vertices"].dim() != 3 or targets["vertices"].shape[0] != B or targets["vertices"].shape[2] != 3:
+            raise ValueError("targets['vertices'] must be [B, Vt, 3]")
         if self.assignment == "device":
             counts = targets["vertex_counts"].to(device=dev, dtype=torch.int64).contiguous()
             tv = targets["vertices"].to(device=dev, dtype=torch.float32).contiguous()
             te = targets["vertex_existence"].to(device=dev, dtype=torch.float32).contiguous()
             tl = targets["edge_labels"].to(device=dev, dtype=torch.float32).contiguous()
+            # the kernels index targets['vertices'][b, :counts[b]] and need counts[b] <= V real columns: clamp (docstring)
+            counts = counts.clamp(min=0, max=min(V, tv.shape[1]))
             w = (self.vertex_weight, self.existence_weight, self.edge_weight)
-            total, parts = _LossDevFn.apply(pv, pe, pp, tv, te, tl, counts, w)
+            scales = self._dp_scales(counts, B, V, pp.shape[1], tl.shape[1], dev)
+            total, parts = _LossDevFn.apply(pv, pe, pp, tv, te, tl, counts, w, scales)
             return {"total_loss": total, "vertex_loss": parts[0], "existence_loss": parts[1], "edge_loss": parts[2]}
         matches = self._hungarian_matching(predictions, targets)
         lens = [len(m[0]) for m in matches]
