@@ -376,6 +376,22 @@ int wf3d_loss_terms(const float* verts, long sample_stride, long vertex_stride, 
                     int n_match, int B, int V, float w_vertex, float w_exist, float w_edge, float* dverts,
                     float* dexist, float* dedge, float* losses, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Row f-2: the step tail of the reference's loop, train.py:141-142 —
+ * torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by torch.optim.Adam.step()
+ * (lr, betas, eps, L2 weight_decay; train.py:96) — over ALL tensors in two launches.
+ * Tables are HOST arrays of `ntensors` device pointers / element counts.  params[i] == NULL marks a tensor that is only
+ * part of the norm and only scaled (the lazily created point_pool_proj, which the reference's optimizer never sees,
+ * SURVEY.md §9 Q1).  grads are scaled in place by min(1, max_norm / (norm + 1e-6)) exactly like clip_grad_norm_
+ * (max_norm <= 0: no clipping); hyper-parameters are doubles so that 1 - beta, the bias corrections and lr / bc1 are
+ * formed in double before their single rounding to fp32, as torch forms them; `step` is the 1-based Adam step of every tensor; total_norm (device scalar, optional)
+ * receives the pre-clip global L2 norm.  ws: wf3d_clip_adam_ws_floats() floats.
+ * ------------------------------------------------------------------------ */
+size_t wf3d_clip_adam_ws_floats(const long* numel, int ntensors);
+int wf3d_clip_adam_step(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                        const long* numel, int ntensors, double max_norm, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int step, float* ws, size_t ws_floats, float* total_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

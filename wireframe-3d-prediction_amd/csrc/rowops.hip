@@ -408,9 +408,9 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
     WF3D_CHECK(!gamma || beta, WF3D_ERR_ARG, "wf3d_ln_act_bwd: gamma without beta");
     hipStream_t st = (hipStream_t)stream;
     if (R == 0) {
-        if (dgamma) hipMemsetAsync(dgamma, 0, D * sizeof(float), st);
-        if (dbeta) hipMemsetAsync(dbeta, 0, D * sizeof(float), st);
-        if (dbias) hipMemsetAsync(dbias, 0, D * sizeof(float), st);
+        if (dgamma) (void)hipMemsetAsync(dgamma, 0, D * sizeof(float), st);
+        if (dbeta) (void)hipMemsetAsync(dbeta, 0, D * sizeof(float), st);
+        if (dbias) (void)hipMemsetAsync(dbias, 0, D * sizeof(float), st);
         return WF3D_OK;
     }
     WF3D_CHECK(dh && z && (dz || dz_sx8), WF3D_ERR_ARG, "wf3d_ln_act_bwd: null pointer");
@@ -584,7 +584,7 @@ extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w,
                            size_t ws_bytes, void* stream) {
     WF3D_CHECK(R >= 0 && D > 0 && ld >= D && out && act >= 0 && act <= 2, WF3D_ERR_ARG, "wf3d_colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (R == 0) { hipMemsetAsync(out, 0, D * sizeof(float), st); return WF3D_OK; }
+    if (R == 0) { (void)hipMemsetAsync(out, 0, D * sizeof(float), st); return WF3D_OK; }
     WF3D_CHECK(x, WF3D_ERR_ARG, "wf3d_colsum: null x");
     const int nrb = colsum_nrb(R);
     WF3D_CHECK(ws && ws_bytes >= (size_t)nrb * D * sizeof(float), WF3D_ERR_WS, "wf3d_colsum: workspace too small");

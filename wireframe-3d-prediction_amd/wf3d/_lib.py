@@ -158,6 +158,10 @@ SIGNATURES = {
     "wf3d_skinny_slab_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "wf3d_skinny_bwd": (c_int, [ctypes.POINTER(SkinnyBwd), c_int, c_int, c_void_p]),
     "wf3d_skinny_reduce": (c_int, [ctypes.POINTER(SkinnyRed), c_int, c_void_p]),
+    "wf3d_clip_adam_ws_floats": (c_size_t, [c_void_p, c_int]),
+    "wf3d_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_void_p,
+                                    c_size_t, c_void_p, c_void_p]),
     "wf3d_edge_prob_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
