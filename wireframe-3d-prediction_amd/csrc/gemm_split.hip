@@ -10,10 +10,13 @@
 // §5.4 rule 21): the 16 lanes of every ds_read_b128 group then hit 16 distinct slots.
 // One 16-B chunk is exactly one MFMA fragment (8 consecutive k of one bf16 plane).
 //
-// Per k16 step a wave reads 2x2 (tiles) x 2 (hi, lo) fragments per operand and issues
-// 2x2x3 v_mfma_f32_32x32x16_bf16:  acc += al*bh + ah*bl + ah*bh  (fp32 accumulate).
-// Two LDS stages: the DMA of slice t+1 is issued before the MFMAs of slice t and is
-// waited for (vmcnt(0), emitted by __syncthreads) only after them.
+// Every product costs three bf16 MFMAs, acc += al*bh + ah*bl + ah*bh (fp32 accumulate).  Kernels in this file:
+//   gemm_split_x16p_kernel / gemm_split_x16_kernel<false>   forward + dgrad: 256x256x32 tile, v_mfma_f32_16x16x32_bf16,
+//                                                            3 A + 2 B LDS stages (persistent / plain launch)
+//   gemm_split_x16_kernel<true>                              wgrad on reduction-major operands (ds_read_b64_tr_b16)
+//   gemm_split_dma3_kernel / gemm_split_tn_kernel            256x128 tile, 32x32x16 MFMA: problems with < 512 tiles /
+//                                                            wgrad outputs that are not multiples of 256
+//   split_reduce_kernel                                      split-K slab fold
 #include <stdlib.h>
 
 #include "wf3d_common.h"
@@ -26,17 +29,6 @@
 #define WF3D_DMA_SCHED 0   // 256x256 kernel: 0 = DMA pieces spread over the slice, 1 = over its first half, 2 = bunched at the top
 #endif
 
-#ifndef WF3D_STAMP
-#define WF3D_STAMP 0       // diagnostic build: per-slice s_memtime stamps around the DMA wait and the barrier (x16 kernel)
-#endif
-#if WF3D_STAMP
-__device__ unsigned long long wf3d_stamp_acc[8];
-extern "C" int wf3d_debug_stamps(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(wf3d_stamp_acc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(wf3d_stamp_acc), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
 
 namespace {
 
@@ -68,117 +60,6 @@ __device__ __forceinline__ void dma16_asm(const float* src, float* lds_wave_base
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(src), "s"(lds) : "memory");      // m0 is reserved: the compiler never keeps a value in it across statements
 }
-
-__global__ __launch_bounds__(256, 2) void gemm_split_dma_kernel(const SplitParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * STILE];     // 64 KB: 2 stages x (A, B)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5, l31 = lane & 31;
-
-    const int nwg = p.nbm * p.nbn;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (vid / p.nbn) * 128, n0 = (vid % p.nbn) * 128;
-    const int ktotal = p.K / SBK;
-    const int kt0 = blockIdx.z * p.kt_per_split;
-    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
-
-    // DMA source pointers: instruction q of this wave fills tile rows (4*wave+q)*8 .. +7;
-    // lane -> row (lane>>3), destination chunk (lane&7), source chunk swizzled.  Rows past
-    // the matrix edge are clamped (their results are never stored).
-    const float* asrc[4];
-    const float* bsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk * 4;
-        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 4;
-    }
-    auto issue = [&](int kt, int stage) {
-        float* As = smem + stage * 2 * STILE + wave * 4 * 8 * SBK;
-        float* Bs = As + STILE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dma16(asrc[q] + kt * SBK, As + q * 8 * SBK);
-            dma16(bsrc[q] + kt * SBK, Bs + q * 8 * SBK);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // fragment addressing: row = tile*32 + l31 -> swizzle term depends on l31 only
-    const int fsw = (l31 >> 1) & 7;
-    if (kt0 < kt1) issue(kt0, 0);
-    __syncthreads();
-    int stage = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        if (kt + 1 < kt1) issue(kt + 1, stage ^ 1);
-        const float* As = smem + stage * 2 * STILE;
-        const float* Bs = As + STILE;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int phi = ((2 * (2 * s2 + h)) ^ fsw) * 4, plo = phi ^ 4;     // float offsets of the hi / lo chunk
-            f32x4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float* pr = As + ((wm * 2 + i) * 32 + l31) * SBK;
-                ah[i] = *reinterpret_cast<const f32x4*>(pr + phi);
-                al[i] = *reinterpret_cast<const f32x4*>(pr + plo);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float* pr = Bs + ((wn * 2 + j) * 32 + l31) * SBK;
-                bh[j] = *reinterpret_cast<const f32x4*>(pr + phi);
-                bl[j] = *reinterpret_cast<const f32x4*>(pr + plo);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();        // vmcnt(0) for the DMA of slice kt+1, and WAR protection of this stage
-        stage ^= 1;
-    }
-
-    const bool split = p.ksplit > 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + (wn * 2 + j) * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + (wm * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[i][j][e];
-                if (split) {
-                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v += bv;
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------
 // Deep-pipelined variant: 256x128 tile, 8 waves (4 x 2, 64x64 each), THREE LDS
@@ -520,321 +401,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_tn_kernel(const SplitParams
     }
 }
 
-// ---------------------------------------------------------------------------
-// 256x256 tile variant: 8 waves (2 x 4), each 128x64 = 4x2 MFMA tiles (128 accumulator
-// registers), TWO LDS stages of 64 KB.  A slice now carries 48 MFMAs per wave (1536 pipe
-// cycles, 3072 per SIMD with two waves), longer than the DMA's issue->landed latency, so
-// a prefetch distance of one slice suffices; per MFMA it needs 25 % fewer global bytes and
-// LDS fragment reads than the 256x128 tile.
-// ---------------------------------------------------------------------------
+// tile constants of the 256x256 kernels below (x16 / x16p): one operand slice = 256 rows x 32 floats = 32 KB
 constexpr int T4_A = 256 * SBK, T4_STAGE = 2 * T4_A;
-
-__global__ __launch_bounds__(512, 2) void gemm_split_dma256_kernel(const SplitParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * T4_STAGE];      // 131,072 B
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows wm*128, cols wn*64
-    const int h = lane >> 5, l31 = lane & 31;
-
-    const int nwg = p.nbm * p.nbn;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 256;
-    const int ktotal = p.K / SBK;
-    const int kt0 = blockIdx.z * p.kt_per_split;
-    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
-
-    const float* asrc[4];
-    const float* bsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + (lane >> 3);
-        const int chunk = ((lane & 7) ^ ((row >> 1) & 7)) * 4;
-        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
-        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
-    }
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fsw = (l31 >> 1) & 7;
-    if (kt0 < kt1) {
-        float* dA = smem + wave * 4 * 8 * SBK;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dma16(asrc[q] + kt0 * SBK, dA + q * 8 * SBK);
-            dma16(bsrc[q] + kt0 * SBK, dA + T4_A + q * 8 * SBK);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    int stage = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool ahead = kt + 1 < kt1;
-        float* dA = smem + (stage ^ 1) * T4_STAGE + wave * 4 * 8 * SBK;
-        float* dB = dA + T4_A;
-        const int kn = (kt + 1) * SBK;
-        const float* As = smem + stage * T4_STAGE;
-        const float* Bs = As + T4_A;
-#if WF3D_DMA_SCHED == 2
-        if (ahead) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dma16(asrc[q] + kn, dA + q * 8 * SBK);
-                dma16(bsrc[q] + kn, dB + q * 8 * SBK);
-            }
-        }
-#endif
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int phi = ((2 * (2 * s2 + h)) ^ fsw) * 4, plo = phi ^ 4;
-            f32x4 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float* pr = As + ((wm * 4 + i) * 32 + l31) * SBK;
-                ah[i] = *reinterpret_cast<const f32x4*>(pr + phi);
-                al[i] = *reinterpret_cast<const f32x4*>(pr + plo);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float* pr = Bs + ((wn * 2 + j) * 32 + l31) * SBK;
-                bh[j] = *reinterpret_cast<const f32x4*>(pr + phi);
-                bl[j] = *reinterpret_cast<const f32x4*>(pr + plo);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-#if WF3D_DMA_SCHED == 0
-                    if (j == 0) {          // one DMA piece after every 6 MFMAs: 4 pieces per k16 step, 8 per slice
-                        const int piece = s2 * 4 + i;
-#else
-                    if (s2 == 0) {         // one DMA piece after every 3 MFMAs of the FIRST k16 step
-                        const int piece = i * 2 + j;
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (ahead && WF3D_DMA_SCHED != 2) {
-                            if (piece < 4) dma16(asrc[piece & 3] + kn, dA + (piece & 3) * 8 * SBK);
-                            else           dma16(bsrc[piece & 3] + kn, dB + (piece & 3) * 8 * SBK);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stage ^= 1;
-    }
-
-    const bool split = p.ksplit > 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + (wn * 2 + j) * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + (wm * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[i][j][e];
-                if (split) {
-                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v += bv;
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// 256x256 tile, FOUR LDS stages of one k16 step each (64-B row slices, 32 KB per stage) and
-// register-pipelined fragments.  The two-stage kernel above starts every k16 step with a
-// burst of 12 ds_read_b128 per wave whose latency nothing covers: the barrier has just put
-// all eight waves in the same phase, so both waves of a SIMD wait together (PMC: MFMA pipe
-// busy 55 %).  Here the fragment reads run two MFMA groups (12 MFMAs) ahead of their use,
-// ACROSS step boundaries: the barrier at the top of step s publishes slice s+1 (not s), so
-// the reads of slice s+1's first fragments are issued while slice s is still being
-// multiplied, and after a barrier the next MFMA's operands are already in registers.
-//   step s:  s_waitcnt vmcnt(4)  (own DMA pieces of slice s+1 landed; s+2's stay in flight)
-//            s_barrier           (slice s+1 visible; stage (s-1)%4 free)
-//            4 groups i=0..3:  reads A(i+2) [or A(i-2) of slice s+1], B half of slice s+1,
-//                              one DMA piece of slice s+3, 6 MFMAs (A tile i x 2 B tiles x 3)
-// LDS image per operand and stage: [256 rows][64 B], chunk' = chunk ^ ((row >> 2) & 3): the
-// 16 lanes of a ds_read_b128 group (16 rows, same chunk) hit 16 distinct 16-B slots.
-// ---------------------------------------------------------------------------
-constexpr int P4_ROWF = 16, P4_T = 256 * P4_ROWF, P4_STAGE = 2 * P4_T;
-
-struct P4Frags {
-    f32x4 ah[4], al[4];          // A tile i of the current (or next) step, slot = i
-    f32x4 bh[2][2], bl[2][2];    // [buffer = step parity][B tile j]
-};
-
-template <int PAR>
-__device__ __forceinline__ void p4_step(f32x16 (&acc)[4][2], P4Frags& f, float* smem, int s, int s1, int a_hi, int a_lo,
-                                        int b_hi, int b_lo, const float* const (&asrc)[2], const float* const (&bsrc)[2],
-                                        int wave) {
-    const float* cur = smem + (s & 3) * P4_STAGE;
-    const float* nxt = smem + ((s + 1) & 3) * P4_STAGE;
-    float* dst = smem + ((s + 3) & 3) * P4_STAGE + wave * 2 * 16 * P4_ROWF;
-    // Branch-free body (one basic block keeps the compiler's lgkmcnt bookkeeping exact): past the
-    // end the DMA re-fetches the last slice into a stage nobody reads again, so there are always
-    // exactly 4 younger pieces in flight at the wait below.
-    const int kn = min(s + 3, s1 - 1) * P4_ROWF;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        {   // A fragments two groups ahead
-            const int t = (i + 2) & 3;
-            const float* base = (i < 2 ? cur : nxt) + t * (32 * P4_ROWF);
-            f.ah[t] = *reinterpret_cast<const f32x4*>(base + a_hi);
-            f.al[t] = *reinterpret_cast<const f32x4*>(base + a_lo);
-        }
-        if (i < 2) {   // B fragments of the next step, one tile per group
-            const float* base = nxt + P4_T + i * (32 * P4_ROWF);
-            f.bh[PAR ^ 1][i] = *reinterpret_cast<const f32x4*>(base + b_hi);
-            f.bl[PAR ^ 1][i] = *reinterpret_cast<const f32x4*>(base + b_lo);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (i < 2) dma16_asm(asrc[i & 1] + kn, dst + (i & 1) * 16 * P4_ROWF);
-        else       dma16_asm(bsrc[i & 1] + kn, dst + P4_T + (i & 1) * 16 * P4_ROWF);
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, f.ah[i]), al = __builtin_bit_cast(bf16x8, f.al[i]);
-        const bf16x8 bh0 = __builtin_bit_cast(bf16x8, f.bh[PAR][0]), bl0 = __builtin_bit_cast(bf16x8, f.bl[PAR][0]);
-        const bf16x8 bh1 = __builtin_bit_cast(bf16x8, f.bh[PAR][1]), bl1 = __builtin_bit_cast(bf16x8, f.bl[PAR][1]);
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[i][1], 0, 0, 0);
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[i][1], 0, 0, 0);
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[i][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-__global__ __launch_bounds__(512, 2) void gemm_split_p4_kernel(const SplitParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * P4_STAGE];      // 131,072 B
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows wm*128, cols wn*64
-    const int h = lane >> 5, l31 = lane & 31;
-
-    const int nwg = p.nbm * p.nbn;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (vid / p.nbn) * 256, n0 = (vid % p.nbn) * 256;
-    const int ktotal = p.K / SBK;
-    const int s0 = blockIdx.z * p.kt_per_split * 2;                       // k16 steps
-    const int s1 = min(ktotal, (int)(blockIdx.z + 1) * p.kt_per_split) * 2;
-
-    // DMA: one instruction = 16 rows x 64 B; wave w stages rows 32w .. 32w+31 of A and of B
-    const float* asrc[2];
-    const float* bsrc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = (wave * 2 + q) * 16 + (lane >> 2);
-        const int chunk = ((lane & 3) ^ ((row >> 2) & 3)) * 4;
-        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
-        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
-    }
-    auto issue = [&](int s) {
-        float* dst = smem + (s & 3) * P4_STAGE + wave * 2 * 16 * P4_ROWF;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) dma16_asm(asrc[q] + s * P4_ROWF, dst + q * 16 * P4_ROWF);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) dma16_asm(bsrc[q] + s * P4_ROWF, dst + P4_T + q * 16 * P4_ROWF);
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // fragment offsets (floats) inside an operand's stage image
-    const int fsw = (l31 >> 2) & 3;
-    const int c_hi = ((2 * h) ^ fsw) * 4, c_lo = ((2 * h + 1) ^ fsw) * 4;
-    const int a_row = (wm * 128 + l31) * P4_ROWF, b_row = (wn * 64 + l31) * P4_ROWF;
-    const int a_hi = a_row + c_hi, a_lo = a_row + c_lo, b_hi = b_row + c_hi, b_lo = b_row + c_lo;
-
-    // prologue: slices s0, s0+1, s0+2 in flight; slice s0 published; first fragments requested
-    const int nsteps = s1 - s0;                                           // even, >= 2
-    issue(s0);
-    issue(s0 + 1);
-    issue(min(s0 + 2, s1 - 1));
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    P4Frags f;
-    {
-        const float* cur = smem + (s0 & 3) * P4_STAGE;
-        const int par = 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f.bh[par][j] = *reinterpret_cast<const f32x4*>(cur + P4_T + j * (32 * P4_ROWF) + b_hi);
-            f.bl[par][j] = *reinterpret_cast<const f32x4*>(cur + P4_T + j * (32 * P4_ROWF) + b_lo);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f.ah[i] = *reinterpret_cast<const f32x4*>(cur + i * (32 * P4_ROWF) + a_hi);
-            f.al[i] = *reinterpret_cast<const f32x4*>(cur + i * (32 * P4_ROWF) + a_lo);
-        }
-    }
-    // The stage ring is indexed by the absolute step number; the DMA sources by the same.
-    for (int s = s0; s < s1; s += 2) {
-        p4_step<0>(acc, f, smem, s, s1, a_hi, a_lo, b_hi, b_lo, asrc, bsrc, wave);
-        p4_step<1>(acc, f, smem, s + 1, s1, a_hi, a_lo, b_hi, b_lo, asrc, bsrc, wave);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
-
-    const bool split = p.ksplit > 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + (wn * 2 + j) * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + (wm * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[i][j][e];
-                if (split) {
-                    p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v += bv;
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // 256x256x32 tile on v_mfma_f32_16x16x32_bf16.  Same LDS image, DMA and two stages as the
@@ -872,7 +440,7 @@ template <bool TN>
 __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParams p) {
     // All 160 KB of LDS: THREE stages for A (the operand streamed from HBM: its slice t+2 is in flight while t
     // is multiplied) and two for B (weights / the other streamed operand: slice t+1).  Measured with in-kernel
-    // stamps (-DWF3D_STAMP) on the two-stage forward/dgrad kernel: 9-35 % of every slice was spent waiting for
+    // stamps (round 1, instrumentation since removed) on the two-stage forward/dgrad kernel: 9-35 % of every slice was spent waiting for
     // the A pieces issued one slice earlier — HBM read latency under the kernel's own C-store traffic is more
     // than one slice (wgrad, which stores almost nothing: 2 %).
     __shared__ __attribute__((aligned(16))) float smem[5 * T4_A];          // 163,840 B
@@ -957,11 +525,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
     asm volatile("" ::: "memory");
 
     int stage = 0, astage = 0;                              // B ring of 2, A ring of 3
-#if WF3D_STAMP
-    unsigned long long st_compute = 0, st_dma = 0, st_bar = 0, st_n = 0, st_dma4 = 0;
-    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_loop_begin = st_prev;
-#endif
     for (int kt = kt0; kt < kt1; ++kt) {
         const int astage2 = astage == 0 ? 2 : astage - 1;                  // (astage + 2) % 3
         float* dA = smem + astage2 * T4_A + wave * 4 * 8 * SBK;            // A(kt+2)
@@ -1015,33 +578,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             __builtin_amdgcn_sched_barrier(0);
             ah = ahn; al = aln;
         }
-#if WF3D_STAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");          // A(kt+1), issued a slice ago
-        const unsigned long long t1b = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");          // + B(kt+1), issued at the top of this slice
-        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        if (kt - kt0 >= 4) st_dma4 += t1b - t1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        st_compute += t1 - st_prev; st_dma += t2 - t1; st_bar += t3 - t2; st_prev = t3; ++st_n;
-#else
-        // B(kt+1) and A(kt+1) landed (all but the 4 youngest pieces = A(kt+2)); this wave's reads of the stages done
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#endif
         stage ^= 1;
         astage = astage == 2 ? 0 : astage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
-#if WF3D_STAMP
-    const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
-#endif
 
     const bool split = p.ksplit > 1;
     const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
@@ -1083,18 +623,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             }
         }
     }
-#if WF3D_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {
-        atomicAdd(&wf3d_stamp_acc[0], st_compute); atomicAdd(&wf3d_stamp_acc[1], st_dma);
-        atomicAdd(&wf3d_stamp_acc[2], st_bar);     atomicAdd(&wf3d_stamp_acc[3], st_n);
-        atomicAdd(&wf3d_stamp_acc[4], t_end - t_loop_end);      // epilogue incl. store drain
-        atomicAdd(&wf3d_stamp_acc[5], t_loop_end - t_loop_begin);
-        atomicAdd(&wf3d_stamp_acc[6], 1ull);
-        atomicAdd(&wf3d_stamp_acc[7], st_dma4);
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1246,142 +774,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
 }
 
-// ---------------------------------------------------------------------------
-// 128x128x32 tile on v_mfma_f32_16x16x32_bf16, 4 waves (2 x 2, 64x64 each = 4 x 4 accumulator tiles), two 32 KB
-// stages = 64 KB of LDS and <= 128 VGPRs: TWO workgroups per CU with independent phases, so one's C write-out
-// and slice-top latencies run under the other's MFMAs.  (The 256x256 kernel owns its CU alone: in-kernel stamps
-// put its write-out at 15-40 % of a tile's time.)  Price: twice the L2->LDS bytes per FLOP.
-// ---------------------------------------------------------------------------
-constexpr int S7_T = 128 * SBK, S7_STAGE = 2 * S7_T;
-
-__global__ __launch_bounds__(256, 2) void gemm_split_x16s_kernel(const SplitParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * S7_STAGE];      // 65,536 B
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r16 = lane & 15, g = lane >> 4;
-
-    const int nwg = p.nbm * p.nbn;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (vid / p.nbn) * 128, n0 = (vid % p.nbn) * 128;
-    const int ktotal = p.K / SBK;
-    const int kt0 = blockIdx.z * p.kt_per_split;
-    const int kt1 = min(ktotal, kt0 + p.kt_per_split);
-
-    const float* asrc[4];
-    const float* bsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + (lane >> 3);
-        const int chunk = ((lane & 7) ^ swz16(row)) * 4;
-        asrc[q] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + chunk;
-        bsrc[q] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + chunk;
-    }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fs = swz16(r16);
-    const int c_hi = ((2 * g) ^ fs) * 4, c_lo = ((2 * g + 1) ^ fs) * 4;
-    const int a_row = (wm * 64 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
-    {
-        float* dA = smem + wave * 4 * 8 * SBK;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dma16_asm(asrc[q] + kt0 * SBK, dA + q * 8 * SBK);
-            dma16_asm(bsrc[q] + kt0 * SBK, dA + S7_T + q * 8 * SBK);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    int stage = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        float* dA = smem + (stage ^ 1) * S7_STAGE + wave * 4 * 8 * SBK;
-        float* dB = dA + S7_T;
-        const int kn = min(kt + 1, kt1 - 1) * SBK;                          // branch-free: last slice re-fetches itself
-        const float* As = smem + stage * S7_STAGE + a_row;
-        const float* Bs = smem + stage * S7_STAGE + S7_T + b_row;
-        f32x4 bh[4], bl[4], ah, al, ahn, aln;
-        al = *reinterpret_cast<const f32x4*>(As + c_lo);
-        bh[0] = *reinterpret_cast<const f32x4*>(Bs + c_hi);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_hi);
-        __builtin_amdgcn_sched_barrier(0);
-        ah = *reinterpret_cast<const f32x4*>(As + c_hi);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bs + j * 16 * SBK + c_lo);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < 3) {
-                ahn = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_hi);
-                aln = *reinterpret_cast<const f32x4*>(As + (i + 1) * 16 * SBK + c_lo);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (i < 2) { dma16_asm(asrc[2 * i] + kn, dA + (2 * i) * 8 * SBK);         dma16_asm(asrc[2 * i + 1] + kn, dA + (2 * i + 1) * 8 * SBK); }
-            else       { dma16_asm(bsrc[2 * i - 4] + kn, dB + (2 * i - 4) * 8 * SBK); dma16_asm(bsrc[2 * i - 3] + kn, dB + (2 * i - 3) * 8 * SBK); }
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), val, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), vah, acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            ah = ahn; al = aln;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stage ^= 1;
-    }
-
-    const bool split = p.ksplit > 1;
-    const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
-    const int colw = n0 + wn * 64 + g * 4;
-    f32x4 bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!split && p.bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][e] = colw + j * 16 + e < p.N ? p.bias[colw + j * 16 + e] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 64 + i * 16 + r16;
-        if (row >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = colw + j * 16;
-            if (col >= p.N) continue;
-            f32x4 v = acc[i][j];
-            float* c = split ? p.slab + ((size_t)blockIdx.z * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
-            if (!split) v += bv[j];
-            if (vec && col + 3 < p.N) {
-                if (!split && p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
-                *reinterpret_cast<f32x4*>(c) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (col + e >= p.N) break;
-                    float o = v[e];
-                    if (!split && p.accumulate) o += c[e];
-                    c[e] = o;
-                }
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
     const size_t total = (size_t)p.M * p.N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -1410,15 +802,19 @@ int cu_count() {
     return n;
 }
 
+// 6 = 256x256 tile on v_mfma_f32_16x16x32_bf16 (gemm_split_x16_kernel / its persistent form): problems with >= 512 tiles;
+// 3 = 256x128 tile, three LDS stages, 32x32x16 MFMA (gemm_split_dma3_kernel): the smaller ones.
+// WF3D_SPLIT_DMA=3|6 forces one of them (tests/test_variants_gpu.py); the other round-1 variants live in
+// scripts/ablation/gemm_split_variants.hip.txt.
 int split_variant(int M, int N) {
     static const int forced = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 7) return forced;
+    if (forced == 3 || forced == 6) return forced;
     return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= 512 ? 6 : 3;
 }
 
 void plan(int M, int N, int K, int& ksplit, int& kt_per) {
     const int v = split_variant(M, N);
-    const int bm = (v >= 3 && v != 7) ? 256 : 128, bn = (v >= 4 && v != 7) ? 256 : 128;
+    const int bm = 256, bn = v == 6 ? 256 : 128;
     const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, bn);
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
@@ -1457,15 +853,13 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     p.A = (const float*)A_sx8; p.B = (const float*)B_sx8; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.accumulate = accumulate;
     const int variant = split_variant(M, N);
-    const bool deep = variant == 3;
-    p.nbm = wf3d_cdiv(M, (variant >= 3 && variant != 7) ? 256 : 128); p.nbn = wf3d_cdiv(N, (variant >= 4 && variant != 7) ? 256 : 128);
+    p.nbm = wf3d_cdiv(M, 256); p.nbn = wf3d_cdiv(N, variant == 6 ? 256 : 128);
     plan(M, N, K, p.ksplit, p.kt_per_split);
     const size_t need = p.ksplit > 1 ? (size_t)p.ksplit * M * N * sizeof(float) : 0;
     if (need && (ws == nullptr || ws_bytes < need)) { p.ksplit = 1; p.kt_per_split = K / SBK; }
     p.slab = p.ksplit > 1 ? (float*)ws : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 7) hipLaunchKernelGGL(gemm_split_x16s_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
-    else if (variant == 6) {
+    if (variant == 6) {
         static const int persist_on = [] { const char* e = getenv("WF3D_SPLIT_PERSIST"); return e ? atoi(e) : 1; }();
         const int cus = cu_count();
         if (persist_on && p.ksplit == 1 && M % 256 == 0 && N % 256 == 0 && K / SBK >= 2 && cus >= 8 && cus % 8 == 0 &&
@@ -1473,11 +867,9 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
             hipLaunchKernelGGL(gemm_split_x16p_kernel, dim3(cus, 1, 1), dim3(512), 0, st, p);
         else
             hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     }
-    else if (variant == 5) hipLaunchKernelGGL(gemm_split_p4_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
-    else if (variant == 4) hipLaunchKernelGGL(gemm_split_dma256_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
-    else if (deep) hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
-    else      hipLaunchKernelGGL(gemm_split_dma_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(256), 0, st, p);
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const size_t total = (size_t)M * N;
