@@ -578,6 +578,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             __builtin_amdgcn_sched_barrier(0);
             ah = ahn; al = aln;
         }
+        // B(kt+1) and A(kt+1) landed (all but the 4 youngest pieces = A(kt+2)); this wave's reads of the stages done
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         stage ^= 1;
         astage = astage == 2 ? 0 : astage + 1;
     }
