@@ -392,6 +392,22 @@ int wf3d_clip_adam_step(float* const* params, float* const* grads, float* const*
                         const long* numel, int ntensors, double max_norm, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int step, float* ws, size_t ws_floats, float* total_norm, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Row f-3: the input pipeline, datasets/building3d.py:95-158.  Clouds are parsed once, normalised once on
+ * the device in float64 (the raw coordinates are UTM metres: colour / 256 for columns [color_lo, color_hi), centroid and
+ * max-norm of xyz, :101-121) and stay resident; every batch is then ONE gather kernel: random rows (:127), flips and the
+ * rotation about z (:130-145) applied in float64 and rounded to fp32 once (:158).  The random choices [B, P] and
+ * aug[b] = {flip_x (+-1), flip_y (+-1), cos t, sin t} come from the host's numpy RNG in the reference's draw order.
+ * Packed layout: cloud i owns rows first[i] .. first[i+1]-1 of raw / out ([rows, C] float64).
+ * ------------------------------------------------------------------------ */
+int wf3d_cloud_normalize(const double* raw, const long* first, int nclouds, int C, int color_lo, int color_hi, int normalize,
+                         double* out, double* centroid, double* max_distance, void* stream);
+int wf3d_cloud_sample(const double* norm, const long* first, const int* cloud, const int* choice, const double* aug, int B,
+                      int P, int C, float* out, void* stream);
+/* HOST function: the numbers of a whitespace-separated text file (.xyz: 8 per row; np.loadtxt, :98) into out[0..max_vals);
+ * returns the count in the file (call again with a larger buffer if > max_vals), -1 unreadable, -2 not a number. */
+long wf3d_parse_floats(const char* path, double* out, long max_vals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,6 +162,9 @@ SIGNATURES = {
     "wf3d_clip_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int, c_void_p,
                                     c_size_t, c_void_p, c_void_p]),
+    "wf3d_cloud_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wf3d_cloud_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_parse_floats": (ctypes.c_long, [ctypes.c_char_p, c_void_p, ctypes.c_long]),
     "wf3d_edge_prob_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
