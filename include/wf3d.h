@@ -408,6 +408,21 @@ int wf3d_cloud_sample(const double* norm, const long* first, const int* cloud, c
  * returns the count in the file (call again with a larger buffer if > max_vals), -1 unreadable, -2 not a number. */
 long wf3d_parse_floats(const char* path, double* out, long max_vals);
 
+/* ------------------------------------------------------------------------
+ * Row f-4: evaluation post-processing behind the path, evaluate.py:74-110 and
+ * eval/ap_calculator.py:8-36.
+ * wf3d_edge_endpoints: for every sample s and every candidate edge e = (i < j < counts[s]) in the model's lexicographic
+ * order: keep[s, e] = probs[s, e] > threshold (:79) and edge_vertices[s, e] = the two predicted end points, higher z first
+ * (:88-89; equal z: vertex j first) — all samples in one launch, so the host needs one copy instead of one per sample.
+ * verts strides in floats (the `vertices` output is a view).  Entries e >= E_s are left untouched.
+ * wf3d_hausdorff_lines: out[n, m] = max(h(P_n, T_m), h(T_m, P_n)) over `sample_points` (<= 32) equidistant points per
+ * segment, point k = start + w_k * diff with np.linspace's weights; float64.
+ * ------------------------------------------------------------------------ */
+int wf3d_edge_endpoints(const float* verts, long sample_stride, long vertex_stride, const int32_t* counts, const float* probs,
+                        int B, int V, int max_e, float threshold, float* edge_vertices, unsigned char* keep, void* stream);
+int wf3d_hausdorff_lines(const double* p_start, const double* p_diff, const double* t_start, const double* t_diff, int N, int M,
+                         int sample_points, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
