@@ -110,6 +110,9 @@ int wf3d_gemm_split_tn(const void* A_sx8, const void* B_sx8, float* C, int Mo, i
 /* out_sx8[r, c] = split(in[r*row_stride + c*col_stride])  (col_stride 1: convert;
  * row_stride 1: transpose-convert, used for W^T) */
 int wf3d_split_rows(const float* in, long row_stride, long col_stride, int R, int C, void* out_sx8, void* stream);
+/* the same for up to 8 matrices in one launch (host arrays of length njobs): a stage's weights, each as W and as W^T */
+int wf3d_split_rows_multi(const float* const* in, const long* row_stride, const long* col_stride, const int* R, const int* C,
+                          void* const* out_sx8, int njobs, void* stream);
 /* out_sx8[C, R] = split(drop(act(LN-affine(in[R, C]))))^T — the wgrad operands (reduction
  * index = row index made contiguous): dW = dY^T·X becomes the NT-form
  * wf3d_gemm_split(dY^T_sx8, X^T_sx8).  mu/gamma NULL skip the respective part;

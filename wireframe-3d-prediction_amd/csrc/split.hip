@@ -45,6 +45,42 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// Up to 8 independent split_rows jobs in ONE launch: the weight matrices of a stage, each in both orientations (W for the
+// forward GEMM, W^T for its dgrad), are split at the top of the forward instead of by 8 launches of ~7 us.
+struct SplitJobs {
+    const float* in[8];
+    float* out[8];
+    long rs[8], cs[8];
+    int R[8], C[8], blk_begin[9];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void split_rows_multi_kernel(const SplitJobs J) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < J.njobs && (int)blockIdx.x >= J.blk_begin[i]) j = i;
+    const int nblk = J.blk_begin[j + 1] - J.blk_begin[j], blk = blockIdx.x - J.blk_begin[j];
+    const float* in = J.in[j];
+    float* out = J.out[j];
+    const long rs = J.rs[j], cs = J.cs[j];
+    const int C = J.C[j];
+    const long groups = (long)J.R[j] * (C / 8);
+    for (long idx = (long)blk * 256 + threadIdx.x; idx < groups; idx += (long)nblk * 256) {
+        const int r = (int)(idx / (C / 8)), g = (int)(idx % (C / 8));
+        const float* p = in + (long)r * rs + (long)g * 8 * cs;
+        float v[8];
+        if (cs == 1 && (((uintptr_t)p) % 16 == 0)) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(long)k * cs];
+        }
+        store_sx8(out + (long)r * C + (long)g * 8, v);
+    }
+}
+
 // LayerNorm statistics + h = act(LN(z)) written in sx8: one wave per row, the row
 // lives in registers (NS slots of 8 columns per lane), z is read from HBM once.
 template <int NS>
@@ -285,6 +321,27 @@ extern "C" int wf3d_split_rows(const float* in, long row_stride, long col_stride
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(split_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, row_stride,
                        col_stride, R, C, (float*)out_sx8);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" int wf3d_split_rows_multi(const float* const* in, const long* row_stride, const long* col_stride, const int* R,
+                                    const int* C, void* const* out_sx8, int njobs, void* stream) {
+    WF3D_CHECK(njobs >= 1 && njobs <= 8 && in && row_stride && col_stride && R && C && out_sx8, WF3D_ERR_ARG,
+               "wf3d_split_rows_multi: 1..8 jobs");
+    SplitJobs J;
+    J.njobs = njobs;
+    int blk = 0;
+    for (int i = 0; i < njobs; ++i) {
+        WF3D_CHECK(in[i] && out_sx8[i] && R[i] > 0 && C[i] > 0 && C[i] % 8 == 0, WF3D_ERR_ARG, "wf3d_split_rows_multi: job %d (C must be a multiple of 8)", i);
+        WF3D_CHECK(((uintptr_t)out_sx8[i] % 16) == 0, WF3D_ERR_ARG, "wf3d_split_rows_multi: job %d output must be 16-byte aligned", i);
+        J.in[i] = in[i]; J.out[i] = (float*)out_sx8[i]; J.rs[i] = row_stride[i]; J.cs[i] = col_stride[i]; J.R[i] = R[i]; J.C[i] = C[i];
+        J.blk_begin[i] = blk;
+        long b = ((long)R[i] * (C[i] / 8) + 255) / 256;
+        blk += (int)(b > 2048 ? 2048 : b);
+    }
+    for (int i = njobs; i <= 8; ++i) J.blk_begin[i] = blk;
+    hipLaunchKernelGGL(split_rows_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, J);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }

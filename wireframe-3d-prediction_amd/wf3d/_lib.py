@@ -93,6 +93,7 @@ SIGNATURES = {
     "wf3d_gemm_split_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_size_t, c_void_p]),
     "wf3d_split_rows": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_split_rows_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "wf3d_split_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_float, c_u32, c_int, c_void_p, c_void_p]),
     "wf3d_ln_prep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_u32, c_void_p,

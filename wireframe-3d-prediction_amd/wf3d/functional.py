@@ -84,6 +84,10 @@ class EncoderFn(torch.autograd.Function):
             x2 = x2.contiguous()
         split = precision == "bf16x3"
         valid = ops.point_valid(x2)
+        # both sx8 orientations (W for the forward GEMM, W^T for its dgrad) of every split layer's weight, one launch
+        widx = [i for i in range(1, n_hidden + 1)
+                if _split_ok(M, params[4 * i].shape[1], split) and _split_ok(M, params[4 * i].shape[0], split)]
+        wsplit = dict(zip(widx, ops.split_weights([params[4 * i] for i in widx]))) if widx else {}
         zs, stats, hs = [], [], []                 # hs[i] = sx8 operand consumed by Linear i+1 (kept for its wgrad)
         a, a_s, pro = x2, None, None
         for i in range(n_hidden + 1):
@@ -94,7 +98,7 @@ class EncoderFn(torch.autograd.Function):
                 # first Linear + LayerNorm + ReLU + split in one pass (K = input_dim <= 8: a pure write of z and h)
                 z, mu, rs, a_s = ops.first_layer_fwd(x2, W, b, params[2], params[3], ACT_RELU)
             elif a_s is not None:
-                z = ops.gemm_split(a_s, ops.split_rows(W), bias=b)
+                z = ops.gemm_split(a_s, wsplit[i][0] if i in wsplit else ops.split_rows(W), bias=b)
                 a_s = None
             else:
                 z = ops.gemm(a, W, NT, bias=b, pro=pro)
@@ -121,6 +125,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.params = params
         ctx.saved = (x2, valid, zs, stats, hs, po.arg_m, po.arg_u, po.cnt)
         ctx.nvalid = po.nvalid
+        ctx.wT = {i: ws[1] for i, ws in wsplit.items()}
         # unused outputs (point_features when only its pools are consumed) must not come back as 268 MB of zeros
         ctx.set_materialize_grads(False)
         pf3 = pf.view(B, N, C)
@@ -195,7 +200,7 @@ class EncoderFn(torch.autograd.Function):
                 grads[4 * i] = ops.gemm(dz, a_prev, TN, pro=pro_prev)
             if i > 0:
                 if dz_s is not None:
-                    dh = ops.gemm_split(dz_s, ops.split_rows(W, transpose=True))     # dgrad: dz · W
+                    dh = ops.gemm_split(dz_s, ctx.wT[i] if i in ctx.wT else ops.split_rows(W, transpose=True))     # dgrad: dz · W
                 else:
                     dh = ops.gemm(dz, W, NN)
             del dz, dz_s
@@ -421,10 +426,12 @@ class EdgeFn(torch.autograd.Function):
             pre, mu0, rs0, delta = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta)
         del Pa, Pb
         if split:
-            z2 = ops.gemm_split(h1, ops.split_rows(M4w), bias=M4b)
+            (M4s, M4t), (M8s, M8t) = ops.split_weights([M4w, M8w])
+            ctx.wT = (M4t, M8t)
+            z2 = ops.gemm_split(h1, M4s, bias=M4b)
             mu2, rs2, h2 = ops.ln_prep(z2, M5g, M5b, ACT_GELU, drop_p=p2_, seed=sd[3])
             s2 = (mu2, rs2)
-            z3 = ops.gemm_split(h2, ops.split_rows(M8w), bias=M8b)
+            z3 = ops.gemm_split(h2, M8s, bias=M8b)
         else:
             h1 = h2 = None
             z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])); s2 = ops.row_stats(z2)
@@ -478,7 +485,7 @@ class EdgeFn(torch.autograd.Function):
             else:
                 G[20] = (ops.gemm_split(ops.split_transpose(dz3_s, in_sx8=True), ops.split_transpose(z2, p2)) if tsplit
                          else ops.gemm(dz3, z2, TN, pro=p2))
-            dh2 = ops.gemm_split(dz3_s, ops.split_rows(M8w, transpose=True))
+            dh2 = ops.gemm_split(dz3_s, ctx.wT[1])
             del dz3, dz3_s
             dz2_s = torch.empty_like(dh2)
             tn2 = _tn_either(dh2, h1)
@@ -489,7 +496,7 @@ class EdgeFn(torch.autograd.Function):
             else:
                 G[16] = (ops.gemm_split(ops.split_transpose(dz2_s, in_sx8=True), ops.split_transpose(pre, p1)) if tsplit
                          else ops.gemm(dz2, pre, TN, pro=p1))
-            dh1 = ops.gemm_split(dz2_s, ops.split_rows(M4w, transpose=True))
+            dh1 = ops.gemm_split(dz2_s, ctx.wT[0])
             del dz2, dz2_s
         else:
             if fused_tail:

@@ -516,6 +516,32 @@ def split_rows(t, transpose=False):
     return out
 
 
+def split_weights(weights):
+    """[(split(W), split(W^T)) for W in weights] — both sx8 orientations of up to 4 weight matrices per launch
+    (the forward GEMM's operand and its dgrad's)."""
+    out = []
+    for i in range(0, len(weights), 4):
+        chunk = weights[i:i + 4]
+        n = 2 * len(chunk)
+        ins, outs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        rs, cs = (ctypes.c_long * n)(), (ctypes.c_long * n)()
+        Rr, Cc = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        res = []
+        for k, W in enumerate(chunk):
+            _need_cuda(W)
+            W = _rows2d(W)
+            N, K = W.shape
+            a = torch.empty(N, K, dtype=torch.float32, device=W.device)
+            b = torch.empty(K, N, dtype=torch.float32, device=W.device)
+            ins[2 * k], outs[2 * k], rs[2 * k], cs[2 * k], Rr[2 * k], Cc[2 * k] = W.data_ptr(), a.data_ptr(), W.stride(0), 1, N, K
+            ins[2 * k + 1], outs[2 * k + 1], rs[2 * k + 1], cs[2 * k + 1], Rr[2 * k + 1], Cc[2 * k + 1] = \
+                W.data_ptr(), b.data_ptr(), 1, W.stride(0), K, N
+            res.append((a, b))
+        check(_lib.load().wf3d_split_rows_multi(ins, rs, cs, Rr, Cc, outs, n, _stream()), "split_rows_multi")
+        out += res
+    return out
+
+
 def ln_prep(z, gamma, beta, act, eps=LN_EPS, drop_p=0.0, seed=0):
     """(mu, rs, h_sx8) with h = drop(act(LayerNorm(z))); z contiguous [R, D], D % 8 == 0."""
     _need_cuda(z, gamma, beta)
