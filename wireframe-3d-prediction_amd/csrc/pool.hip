@@ -11,6 +11,8 @@
 // LDS tree; the N axis is split over blockIdx.y so that thousands of workgroups fill the chip, and a tiny second
 // kernel folds the splits.  Every fold keeps torch.max's first-max rule (equal values: the smaller n wins).
 // pool4_partial_kernel (any C): thread = channel, 4-byte loads — the fallback.
+#include <stdlib.h>
+
 #include "wf3d_common.h"
 
 namespace {
@@ -307,7 +309,8 @@ bool pool_v4(const float* pf, int C) { return C % 64 == 0 && ((uintptr_t)pf % 16
 int pool_nsplit(int B, int N, int C) {
     // v4 kernel: C/64 workgroups per (cloud, split), >= 64 rows per wave; fallback: C/256 per (cloud, split)
     const int cb = C % 64 == 0 ? C / 64 : wf3d_cdiv(C, 256);
-    int ns = (C % 64 == 0 ? 4096 : 2048) / (B * cb > 0 ? B * cb : 1);
+    static const int tgt = [] { const char* e = getenv("WF3D_POOL_WGS"); return e ? atoi(e) : 2048; }();   // sweep 1024..16384 in situ: 64..71 us, flat (scripts/micro/pool_sweep.sh)
+    int ns = (C % 64 == 0 ? tgt : 2048) / (B * cb > 0 ? B * cb : 1);
     const int cap = wf3d_cdiv(N, C % 64 == 0 ? 256 : 32);
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
