@@ -81,17 +81,25 @@ __global__ __launch_bounds__(256) void split_rows_multi_kernel(const SplitJobs J
     }
 }
 
-// LayerNorm statistics + h = act(LN(z)) written in sx8: one wave per row, the row
-// lives in registers (NS slots of 8 columns per lane), z is read from HBM once.
-template <int NS>
+// LayerNorm statistics + h = act(LN(z)) written in sx8: LPR lanes per row (64: one wave per row; 32: two rows per wave,
+// for D <= 256 where 8 columns per lane would leave half of the wave idle), the row lives in registers (NS slots of 8
+// columns per lane), z is read from HBM once.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NS, int LPR = 64>
 __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ z, int R, int D,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int act, float eps, uint32_t seed, uint32_t thresh, float dscale,
                                                        float* __restrict__ mu, float* __restrict__ rs,
                                                        float* __restrict__ h_sx8) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= R) return;
+    const int lane = threadIdx.x & (LPR - 1);
+    const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (row >= R) return;                     // whole rows (aligned lane groups) leave together: the shuffles below stay inside a row
     const float* p = z + (size_t)row * D;
     float v[NS][8];
     float s = 0.f;
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
             for (int j = 0; j < 4; ++j) { v[i][j] = a[j]; v[i][4 + j] = b[j]; s += a[j] + b[j]; }
         }
     }
-    const float mean = wf3d_wave_sum(s) / (float)D;
+    const float mean = row_sum<LPR>(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
     }
-    const float rstd = 1.0f / sqrtf(wf3d_wave_sum(q) / (float)D + eps);
+    const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)D + eps);
     if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
@@ -363,7 +371,10 @@ extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, co
 #define WF3D_LP(NS_)                                                                                              \
     hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(wf3d_cdiv(R, 4)), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
                        drop_seed, thresh, dscale, mu, rs, (float*)h_sx8)
-    if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
+    if (D <= 256)      // two rows per wave
+        hipLaunchKernelGGL((ln_prep_kernel<1, 32>), dim3(wf3d_cdiv(R, 8)), dim3(256), 0, st, z, R, D, gamma, beta, act, eps,
+                           drop_seed, thresh, dscale, mu, rs, (float*)h_sx8);
+    else if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
 #undef WF3D_LP
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
