@@ -103,41 +103,7 @@ def out_errs(got, want, keys=("vertices", "existence_probabilities", "edge_probs
     return res
 
 
-def capture_decisions(out, model, border=5e-7):
-    """Read the piecewise-constant decisions the HIP forward took (ReLU masks of every LayerNorm+ReLU,
-    pool arg-max rows) off the autograd nodes of a PointCloudToWireframe output dict, BEFORE backward.
-
-    Returns (frozen dict for oracle.model_forward(frozen=...), n_border): n_border counts activations
-    whose LayerNorm output lies within `border` of 0 — there the mask recomputed here could differ from
-    the one the kernels take (they evaluate the same fp32 expression in their own order), so a
-    decision-frozen comparison is only meaningful on inputs with n_border == 0."""
-    relu, n_border = {}, 0
-
-    def mask(name, z, mu, rs):
-        nonlocal n_border
-        sd = model.state_dict()
-        g, b = sd[name + ".weight"], sd[name + ".bias"]
-        v = ((z.double() - mu.double()[:, None]) * rs.double()[:, None]) * g.double() + b.double()
-        n_border += int((v.abs() < border).sum())
-        relu[name] = (v > 0).cpu()
-
-    vfn = out["existence_probabilities"].grad_fn
-    ffn = out["global_features"].grad_fn
-    assert type(vfn).__name__.startswith("VertexFn") and type(ffn).__name__.startswith("FusionFn")
-    efn = ffn.next_functions[0][0]
-    assert type(efn).__name__.startswith("EncoderFn")
-    x2, valid, zs, stats, hs, arg_m, arg_u, cnt = efn.saved
-    for i, (z, (mu, rs)) in enumerate(zip(zs, stats)):
-        mask(f"encoder.mlp.{4 * i + 1}", z, mu, rs)
-    pooled, f0, s0, f3, s3 = ffn.saved
-    mask("encoder.feature_fusion.1", f0, *s0)
-    mask("encoder.feature_fusion.4", f3, *s3)
-    pooled_v, e, z1, s1, z2, s2, z3, s3v, c, z4, s4, d = vfn.saved
-    for k, (z, s) in enumerate(((z1, s1), (z2, s2), (z3, s3v), (z4, s4)), start=1):
-        mask(f"vertex_predictor.vertex_mlp{k}.1", z, *s)
-    frozen = {"relu": relu,
-              "argmax": {"enc_masked": arg_m.long().cpu(), "vert_unmasked": arg_u.long().cpu()}}
-    return frozen, n_border
+from oracle.frozen import capture_decisions  # noqa: E402,F401  (shared with __graft_entry__.smoke)
 
 
 def check_grad_summaries(gold, named_grads, tol, skip=()):
