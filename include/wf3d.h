@@ -83,6 +83,10 @@ typedef struct wf3d_gemm_t {
     int accumulate;      /* C += result instead of C = result                   */
     void* ws;            /* split-K slabs, wf3d_gemm_ws_bytes() bytes, or NULL  */
     size_t ws_bytes;
+    int x3;              /* 0: exact fp32 MFMA.  1: bf16x3 arithmetic — the fp32 operands (after the prologue) are
+                            split into bf16 (hi, lo) while they are staged into LDS and multiplied as
+                            hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; relative error
+                            ~2^-16 per product).  Ignored for M <= 64 (32-row tile).                       */
 } wf3d_gemm_t;
 
 size_t wf3d_gemm_ws_bytes(int M, int N, int K, int layout);

@@ -524,3 +524,60 @@ def test_split_gemms_accumulate_into_out_at_encoder_launch_shapes(ops):
     want2 = out2.double() + At.double().T @ Bt.double()
     ops.gemm_split_tn(ops.split_rows(At), ops.split_rows(Bt), out=out2, accumulate=True)
     assert torch.equal(out2.double(), want2)
+
+
+# ---- x3: bf16x3 arithmetic on fp32 operands, split while they are staged into LDS ---------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 100), (2048, 512, 512), (2048, 256, 512), (2048, 512, 3),
+                                   (129, 257, 33), (1000, 512, 8), (65, 96, 1031), (8192, 1536, 512), (512, 512, 4096)])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_x3_layouts(ops, M, N, K, layout):
+    A = rnd(M, K, seed=11)
+    B = rnd(N, K, seed=12)
+    bias = rnd(N, seed=13)
+    want = ref64(lambda a, b, c: a @ b.T + c, A, B, bias)
+    if layout == ops.NT:
+        got = ops.gemm(A, B, ops.NT, bias=bias, x3=True)
+    elif layout == ops.NN:
+        got = ops.gemm(A, B.T.contiguous(), ops.NN, bias=bias, x3=True)
+    else:
+        got = ops.gemm(A.T.contiguous(), B.T.contiguous(), ops.TN, bias=bias, x3=True)
+    assert rel(got, want) < TOL_SPLIT
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(192, 160, 72), (2048, 192, 40), (77, 130, 19)])
+def test_gemm_x3_exact_on_integer_data(ops, layout, M, N, K):
+    # small integers are exact in bf16 (lo part 0) and their products/sums exact in fp32: any mis-placed
+    # element of the transposing LDS image shows up as an exact mismatch
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randint(-8, 9, (M, K), generator=g).float().to(dev())
+    B = torch.randint(-8, 9, (N, K), generator=g).float().to(dev())
+    want = (A.double() @ B.double().T).float()
+    if layout == ops.NT:
+        got = ops.gemm(A, B, ops.NT, x3=True)
+    elif layout == ops.NN:
+        got = ops.gemm(A, B.T.contiguous(), ops.NN, x3=True)
+    else:
+        got = ops.gemm(A.T.contiguous(), B.T.contiguous(), ops.TN, x3=True)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("act", [0, 2])
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 256), (333, 130, 68)])
+def test_gemm_x3_ln_prologue_addend_accumulate(ops, act, M, N, K):
+    z = rnd(M, K, seed=21, scale=2.0) + 0.5
+    W = rnd(N, K, seed=22)
+    gamma, beta = rnd(K, seed=23) * 0.3 + 1.0, rnd(K, seed=24) * 0.2
+    add = rnd(M, N, seed=25)
+    mu, rs = ops.row_stats(z)
+    pro = ops.Pro(act, mu, rs, gamma, beta)
+    h = ref64(lambda zz, g_, b_: ln_ref(zz, g_, b_, act), z, gamma, beta)
+    want = h @ W.double().cpu().T + add.double().cpu()
+    got = ops.gemm(z, W, ops.NT, addend=add, pro=pro, x3=True)
+    assert rel(got, want) < TOL_SPLIT
+    ops.gemm(z, W, ops.NT, out=got, accumulate=True, pro=pro, x3=True)          # got = 2*(h W^T) + add
+    assert rel(got, 2 * (h @ W.double().cpu().T) + add.double().cpu()) < TOL_SPLIT
+    # TN: dW[N,K] = dz^T · pro(z)
+    dz = rnd(M, N, seed=26)
+    gw = ops.gemm(dz, z, ops.TN, pro=pro, x3=True)
+    assert rel(gw, dz.double().cpu().T @ h) < TOL_SPLIT

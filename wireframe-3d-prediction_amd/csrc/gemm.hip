@@ -6,9 +6,12 @@
 // 32x32 built from v_mfma_f32_32x32x2_f32 (exact f32 FMA chain, 64 FLOP/clk/SIMD,
 // MI355X_MICROARCH.md "Matrix cores").  K is walked in BK=32 slices that are
 // staged global -> registers -> LDS with a two-stage LDS ring: the global loads
-// of slice t+1 are issued before the MFMAs of slice t and written to the other
-// LDS stage after them (async-STAGE split, cdna_hip_programming.md T14), one
-// barrier per slice.
+// of slices t+1 .. t+R (R = 2 or 3 register sets) are in flight under the MFMAs
+// of slice t; slice t+1 is written to the other LDS stage after them
+// (async-STAGE split, cdna_hip_programming.md T14), one barrier per slice.
+// With wf3d_gemm_t.x3 the same kernel multiplies in bf16x3: the staging pass
+// splits each fp32 value into bf16 (hi, lo) and the loop issues three
+// v_mfma_f32_32x32x16_bf16 per product.
 //
 // LDS images (per operand, chosen by its global layout so that global reads are
 // always 16-B coalesced and no transposition is ever needed):
@@ -24,6 +27,8 @@
 // into the staging pass of the activation operand, so normalised activations
 // are never written to HBM: only pre-LN z and per-row (mu, rstd) exist.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "wf3d_common.h"
 
@@ -119,6 +124,46 @@ __device__ __forceinline__ void store_tile(float* lds, int tid, const f32x4 (&v)
     }
 }
 
+// ---- staging, X3 mode: split fp32 registers into bf16 (hi, lo) pairs and write the k-contiguous "sx8" image
+// [rows][36 floats], each 32-B group = [8 x hi | 8 x lo] of 8 consecutive k — the image the bf16x3 MFMA loop reads.
+// A k-contiguous operand gives each thread 4 consecutive k of one row (two 8-B writes); a row-contiguous operand
+// gives 4 consecutive rows at one k, which is transposed here with 2-B writes.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int ROWS, bool KC>
+__device__ __forceinline__ void store_tile_x3(float* lds, int tid, const f32x4 (&v)[ROWS / 32]) {
+    constexpr int NV = ROWS / 32;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = (__bf16)v[i][j];
+                lo[j] = (__bf16)(v[i][j] - (float)hi[j]);
+            }
+            float* g = &lds[((tid >> 3) + 32 * i) * LDK + ((tid & 7) >> 1) * 8 + (tid & 1) * 2];
+            *reinterpret_cast<bf16x4*>(g) = hi;
+            *reinterpret_cast<bf16x4*>(g + 4) = lo;
+        }
+    } else {
+        constexpr int TPR = ROWS / 4;
+        constexpr int KPP = 256 / TPR;
+        __bf16* l16 = reinterpret_cast<__bf16*>(lds);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int kk = tid / TPR + KPP * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __bf16 hi = (__bf16)v[i][j];
+                const __bf16 lo = (__bf16)(v[i][j] - (float)hi);
+                __bf16* g = l16 + (((tid % TPR) * 4 + j) * LDK + (kk >> 3) * 8) * 2 + (kk & 7);
+                g[0] = hi;
+                g[8] = lo;
+            }
+        }
+    }
+}
+
 // ---- fragment read: 4 consecutive-k values of one 32-row tile for this lane --
 template <int ROWS, bool KC>
 __device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int ks, int h) {
@@ -146,11 +191,21 @@ __device__ __forceinline__ void load_tile_fast(const float* __restrict__ p0, int
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool FAST, bool SPLIT>
+// compile-time unrolled steps u = U .. N-1 (register sets are indexed by u and must stay in registers); a step
+// returning false ends the sequence
+template <int U, int N, class F>
+__device__ __forceinline__ void static_steps(F&& f) {
+    if constexpr (U < N) {
+        if (!f(std::integral_constant<int, U>{})) return;
+        static_steps<U + 1, N>(f);
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool FAST, bool SPLIT, bool X3, int R>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int m0, int n0, int kt0, int kt1) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
-    constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
+    constexpr int A_SZ = (A_KC || X3) ? BM * LDK : BK * BM;
+    constexpr int B_SZ = (B_KC || X3) ? BN * LDK : BK * BN;
     constexpr int NVA = BM / 32, NVB = BN / 32;
     constexpr bool PRO_A = PRO && A_KC;     // NT: activation operand is A [M,K]
     constexpr bool PRO_B = PRO && !A_KC;    // TN: activation operand is B [K,N]
@@ -185,28 +240,38 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
             if (gcol + j < p.N) { gam_b[j] = p.pgam[gcol + j]; bet_b[j] = p.pbet[gcol + j]; }
     }
 
-    f32x4 ra[NVA], rb[NVB];
-    f32x4 pg = {1.f, 1.f, 1.f, 1.f}, pbv = {0.f, 0.f, 0.f, 0.f};   // PRO_A: gamma/beta of this tile's k columns
-    float mu_b[NVB], rs_b[NVB];                                     // PRO_B: stats of this tile's k rows
-    auto fetch = [&](int kt) {
+    // R register sets: the global loads of slices t+1 .. t+R are in flight while slice t is multiplied (the launches
+    // this kernel serves run one or two workgroups per CU, so a slice's load latency — about 1.3 us measured,
+    // whatever the MFMA shape — is hidden by depth, not by occupancy).  LDS keeps two stages.
+    struct Regs {
+        f32x4 ra[NVA], rb[NVB];
+        f32x4 pg, pbv;                  // PRO_A: gamma/beta of this slice's k columns
+        float mu_b[NVB], rs_b[NVB];     // PRO_B: stats of this slice's k rows
+    };
+    Regs S[R];
+    auto fetch = [&](int kt, Regs& r) {
         const int k0 = kt * BK;
         if (FAST) {
-            load_tile_fast<BM, A_KC>(pa0, p.lda, k0, ra);
-            load_tile_fast<BN, B_KC>(pb0, p.ldb, k0, rb);
+            load_tile_fast<BM, A_KC>(pa0, p.lda, k0, r.ra);
+            load_tile_fast<BN, B_KC>(pb0, p.ldb, k0, r.rb);
         } else {
-            load_tile<BM, A_KC>(p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid, ra);
-            load_tile<BN, B_KC>(p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid, rb);
+            load_tile<BM, A_KC>(p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid, r.ra);
+            load_tile<BN, B_KC>(p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid, r.rb);
         }
-        if (PRO_A && p.has_affine) {
-            const int k = k0 + (tid & 7) * 4;
-            if (FAST) {
-                pg = *reinterpret_cast<const f32x4*>(p.pgam + k);
-                pbv = *reinterpret_cast<const f32x4*>(p.pbet + k);
-            } else {
+        if (PRO_A) {
+            r.pg = f32x4{1.f, 1.f, 1.f, 1.f};
+            r.pbv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.has_affine) {
+                const int k = k0 + (tid & 7) * 4;
+                if (FAST) {
+                    r.pg = *reinterpret_cast<const f32x4*>(p.pgam + k);
+                    r.pbv = *reinterpret_cast<const f32x4*>(p.pbet + k);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    pg[j] = k + j < p.K ? p.pgam[k + j] : 1.f;
-                    pbv[j] = k + j < p.K ? p.pbet[k + j] : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        r.pg[j] = k + j < p.K ? p.pgam[k + j] : 1.f;
+                        r.pbv[j] = k + j < p.K ? p.pbet[k + j] : 0.f;
+                    }
                 }
             }
         }
@@ -215,12 +280,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
             for (int i = 0; i < NVB; ++i) {
                 const int k = k0 + tid / TPRB + KPPB * i;          // = row of the activation matrix
                 const bool ok = p.has_ln && (FAST || k < p.K);
-                mu_b[i] = ok ? p.pmu[k] : 0.f;
-                rs_b[i] = ok ? p.prs[k] : 1.f;
+                r.mu_b[i] = ok ? p.pmu[k] : 0.f;
+                r.rs_b[i] = ok ? p.prs[k] : 1.f;
             }
         }
     };
-    auto commit = [&](int kt, int stage) {
+    auto commit = [&](int kt, Regs& r, int stage) {
         float* As = smem + stage * (A_SZ + B_SZ);
         float* Bs = As + A_SZ;
         if (PRO_A) {
@@ -230,8 +295,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
                 const int grow = m0 + (tid >> 3) + 32 * i;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    ra[i][j] = pro_one<ACT>(ra[i][j], mu_a[i], rs_a[i], pg[j], pbv[j], p, grow, k + j,
-                                            FAST || (grow < p.M && k + j < p.K));
+                    r.ra[i][j] = pro_one<ACT>(r.ra[i][j], mu_a[i], rs_a[i], r.pg[j], r.pbv[j], p, grow, k + j,
+                                              FAST || (grow < p.M && k + j < p.K));
             }
         }
         if (PRO_B) {
@@ -241,12 +306,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
                 const int k = kt * BK + tid / TPRB + KPPB * i;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    rb[i][j] = pro_one<ACT>(rb[i][j], mu_b[i], rs_b[i], gam_b[j], bet_b[j], p, k, gcol + j,
-                                            FAST || (k < p.K && gcol + j < p.N));
+                    r.rb[i][j] = pro_one<ACT>(r.rb[i][j], r.mu_b[i], r.rs_b[i], gam_b[j], bet_b[j], p, k, gcol + j,
+                                              FAST || (k < p.K && gcol + j < p.N));
             }
         }
-        store_tile<BM, A_KC>(As, tid, ra);
-        store_tile<BN, B_KC>(Bs, tid, rb);
+        if (X3) {
+            store_tile_x3<BM, A_KC>(As, tid, r.ra);
+            store_tile_x3<BN, B_KC>(Bs, tid, r.rb);
+        } else {
+            store_tile<BM, A_KC>(As, tid, r.ra);
+            store_tile<BN, B_KC>(Bs, tid, r.rb);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -257,19 +327,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (kt0 < kt1) {
-        fetch(kt0);
-        commit(kt0, 0);
-    }
-    __syncthreads();
-
-    int stage = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = kt + 1 < kt1;
-        if (more) fetch(kt + 1);                       // global loads in flight under the MFMAs
+    auto multiply = [&](int stage) {
         const float* As = smem + stage * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
-        if (SPLIT) {
+        if (SPLIT || X3) {
             // bf16x3 split precision: each 32-B group of a staged row holds [8 x hi | 8 x lo] bf16 of 8
             // consecutive k; a*b ~= ah*bh + ah*bl + al*bh (fp32 accumulate), v_mfma_f32_32x32x16_bf16.
 #pragma unroll
@@ -298,24 +359,59 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
             }
         } else {
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            f32x4 fa[TM], fb[TN];
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + l31, ks, h);
+                for (int i = 0; i < TM; ++i) fa[i] = read_frag<BM, A_KC>(As, (wm * TM + i) * 32 + l31, ks, h);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + l31, ks, h);
+                for (int j = 0; j < TN; ++j) fb[j] = read_frag<BN, B_KC>(Bs, (wn * TN + j) * 32 + l31, ks, h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            }
         }
+    };
+
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        static_steps<0, R>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (u < nk) fetch(kt0 + u, S[u]);
+            return true;
+        });
+        commit(kt0, S[0], 0);
+    }
+    __syncthreads();
+
+    if (nk <= R) {
+        // short reduction (the K = 3 coordinate products, split-K tails): every slice is already in flight
+        static_steps<0, R>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (u >= nk) return false;
+            multiply(u & 1);
+            if (u + 1 < nk) commit(kt0 + u + 1, S[(u + 1) % R], (u + 1) & 1);
+            __syncthreads();
+            return true;
+        });
+    } else {
+        // past the end the fetch is clamped to the last slice (a harmless re-read that is never committed): the
+        // loop body stays branch-free around the loads, so the compiler's vmcnt waits stay counted
+        for (int s0 = 0; s0 < nk; s0 += R) {
+            static_steps<0, R>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int cur = s0 + u;
+                if (cur >= nk) return false;
+                fetch(min(kt0 + cur + R, kt1 - 1), S[u]);       // set u was committed one slice ago
+                multiply(cur & 1);
+                if (cur + 1 < nk) commit(kt0 + cur + 1, S[(u + 1) % R], (cur + 1) & 1);
+                __syncthreads();
+                return true;
+            });
         }
-        if (more) commit(kt + 1, stage ^ 1);
-        __syncthreads();
-        stage ^= 1;
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -346,11 +442,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
     }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool SPLIT = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_KC, bool B_KC, int ACT, bool PRO, bool SPLIT = false, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
-    constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
+    constexpr int A_SZ = (A_KC || X3) ? BM * LDK : BK * BM;
+    constexpr int B_SZ = (B_KC || X3) ? BN * LDK : BK * BN;
+    // register sets of slices in flight (gemm_body): what fits 256 VGPRs without spilling next to the accumulators
+    constexpr int R = TM * TN == 1 ? 3 : (PRO ? 1 : 2);
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
 
     // XCD-aware tile order: blocks bid, bid+8, ... share an XCD (round-robin
@@ -370,8 +468,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // FAST: every staged tile of this workgroup lies fully inside A and B and is
     // 16-B loadable -> branch-free staging (block-uniform choice)
     const bool fast = p.vecA && p.vecB && p.vecP && (m0 + BM <= p.M) && (n0 + BN <= p.N) && (kt1 * BK <= p.K);
-    if (fast) gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, true, SPLIT>(p, smem, m0, n0, kt0, kt1);
-    else      gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, false, SPLIT>(p, smem, m0, n0, kt0, kt1);
+    if (fast) gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, true, SPLIT, X3, R>(p, smem, m0, n0, kt0, kt1);
+    else      gemm_body<WAVES_M, WAVES_N, TM, TN, A_KC, B_KC, ACT, PRO, false, SPLIT, X3, R>(p, smem, m0, n0, kt0, kt1);
 }
 
 // split-K combine: deterministic slab sum + epilogue terms
@@ -417,17 +515,25 @@ inline bool mid_tile(int M, int N, int K) {
     return M > 64 && t128 < 192 && t64 >= 128 && K <= 2048;
 }
 
-template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int ACT, bool PRO>
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int ACT, bool PRO, bool X3 = false>
 void launch(const GemmParams& p, hipStream_t st) {
     dim3 grid(p.nbm * p.nbn, 1, p.ksplit);
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKC, BKC, ACT, PRO>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AKC, BKC, ACT, PRO, false, X3>), grid, dim3(256), 0, st, p);
 }
 
+// kind: 1 = 32 x 128, 2 = 64 x 64, 0 = 128 x 128.  x3 (bf16x3 arithmetic on fp32 operands, split while staging) exists
+// for the two larger tiles only: the 32-row tile serves launches that are weight-streaming bound.
 template <bool AKC, bool BKC, int ACT, bool PRO>
-void launch_tile(const GemmParams& p, int kind, hipStream_t st) {       // kind: 1 = 32 x 128, 2 = 64 x 64, 0 = 128 x 128
+void launch_tile(const GemmParams& p, int kind, bool x3, hipStream_t st) {
     if (kind == 1)      launch<1, 4, 1, 1, AKC, BKC, ACT, PRO>(p, st);
-    else if (kind == 2) launch<2, 2, 1, 1, AKC, BKC, ACT, PRO>(p, st);
-    else                launch<2, 2, 2, 2, AKC, BKC, ACT, PRO>(p, st);
+    else if (kind == 2) { if (x3) launch<2, 2, 1, 1, AKC, BKC, ACT, PRO, true>(p, st); else launch<2, 2, 1, 1, AKC, BKC, ACT, PRO>(p, st); }
+    else                { if (x3) launch<2, 2, 2, 2, AKC, BKC, ACT, PRO, true>(p, st); else launch<2, 2, 2, 2, AKC, BKC, ACT, PRO>(p, st); }
+}
+
+template <int ACT, bool PRO>
+void launch_tn(const GemmParams& p, bool x3, hipStream_t st) {
+    if (x3) launch<2, 2, 2, 2, false, false, ACT, PRO, true>(p, st);
+    else    launch<2, 2, 2, 2, false, false, ACT, PRO>(p, st);
 }
 
 }  // namespace
@@ -490,18 +596,19 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int act = d->pro_enable ? d->pro_act : 0;
     const bool pro = d->pro_enable != 0;
+    const bool x3 = d->x3 != 0;
     if (d->layout == WF3D_NT) {
-        if (!pro)                         launch_tile<true, true, 0, false>(p, kind, st);
-        else if (act == WF3D_ACT_RELU)    launch_tile<true, true, WF3D_ACT_RELU, true>(p, kind, st);
-        else if (act == WF3D_ACT_GELU)    launch_tile<true, true, WF3D_ACT_GELU, true>(p, kind, st);
-        else                              launch_tile<true, true, WF3D_ACT_NONE, true>(p, kind, st);
+        if (!pro)                         launch_tile<true, true, 0, false>(p, kind, x3, st);
+        else if (act == WF3D_ACT_RELU)    launch_tile<true, true, WF3D_ACT_RELU, true>(p, kind, x3, st);
+        else if (act == WF3D_ACT_GELU)    launch_tile<true, true, WF3D_ACT_GELU, true>(p, kind, x3, st);
+        else                              launch_tile<true, true, WF3D_ACT_NONE, true>(p, kind, x3, st);
     } else if (d->layout == WF3D_NN) {
-        launch_tile<true, false, 0, false>(p, kind, st);
+        launch_tile<true, false, 0, false>(p, kind, x3, st);
     } else {
-        if (!pro)                         launch<2, 2, 2, 2, false, false, 0, false>(p, st);
-        else if (act == WF3D_ACT_RELU)    launch<2, 2, 2, 2, false, false, WF3D_ACT_RELU, true>(p, st);
-        else if (act == WF3D_ACT_GELU)    launch<2, 2, 2, 2, false, false, WF3D_ACT_GELU, true>(p, st);
-        else                              launch<2, 2, 2, 2, false, false, WF3D_ACT_NONE, true>(p, st);
+        if (!pro)                         launch_tn<0, false>(p, x3, st);
+        else if (act == WF3D_ACT_RELU)    launch_tn<WF3D_ACT_RELU, true>(p, x3, st);
+        else if (act == WF3D_ACT_GELU)    launch_tn<WF3D_ACT_GELU, true>(p, x3, st);
+        else                              launch_tn<WF3D_ACT_NONE, true>(p, x3, st);
     }
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {

@@ -29,6 +29,7 @@ class GemmDesc(ctypes.Structure):
         ("drop_p", c_float), ("drop_seed", c_u32),
         ("accumulate", c_int),
         ("ws", c_void_p), ("ws_bytes", c_size_t),
+        ("x3", c_int),
     ]
 
 

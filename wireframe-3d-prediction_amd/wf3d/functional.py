@@ -407,15 +407,20 @@ class EdgeFn(torch.autograd.Function):
         pf_, pa_, p1_, p2_ = (float(x) for x in drop_ps)   # vertex_proj.5, attention, edge_mlp.3, edge_mlp.7
         cv = ops.edge_gather_verts(verts, meta)
         za = ops.gemm(cv, P0w, NT, bias=P0b); sa = ops.row_stats(za)
-        zb = ops.gemm(za, P3w, NT, bias=P3b, pro=Pro(ACT_GELU, sa[0], sa[1], P1g, P1b)); sb = ops.row_stats(zb)
+        # per-vertex Linears (sum-of-counts rows): in bf16x3 mode the fp32 operands of the forward (NT) products are
+        # split inside the GEMM's staging pass (x3).  The K = 3 coordinate products and the backward's NN / TN
+        # products stay on fp32 MFMA: their row-contiguous operands would have to be transposed while staged, which
+        # measured slower than the fp32 loop it replaces (26 -> 31 us, 48 -> 70 us per launch at cfg2).
+        x3 = precision == "bf16x3"
+        zb = ops.gemm(za, P3w, NT, bias=P3b, pro=Pro(ACT_GELU, sa[0], sa[1], P1g, P1b), x3=x3); sb = ops.row_stats(zb)
         f = ops.ln_act_apply(zb, sb[0], sb[1], P4g, P4b, ACT_NONE, drop_p=pf_, seed=sd[0])
-        qkv = ops.gemm(f, Aw, NT, bias=Ab)
+        qkv = ops.gemm(f, Aw, NT, bias=Ab, x3=x3)
         cx, lse = ops.attn_fwd(qkv, meta, H, heads, pa_, sd[1])
-        Fm = ops.gemm(cx, Ow, NT, bias=Ob, addend=f)                     # residual (EdgePredictor.py:114)
+        Fm = ops.gemm(cx, Ow, NT, bias=Ob, addend=f, x3=x3)              # residual (EdgePredictor.py:114)
         Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + 3], M0w[:, 2 * H + 3:2 * H + 6]
-        Pa = ops.gemm(Fm, Wa, NT, bias=M0b)
+        Pa = ops.gemm(Fm, Wa, NT, bias=M0b, x3=x3)
         ops.gemm(cv, Wc, NT, out=Pa, accumulate=True)
-        Pb = ops.gemm(Fm, Wb, NT)
+        Pb = ops.gemm(Fm, Wb, NT, x3=x3)
         ops.gemm(cv, Wd, NT, out=Pb, accumulate=True)
         # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
         split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
@@ -434,8 +439,8 @@ class EdgeFn(torch.autograd.Function):
             z3 = ops.gemm_split(h2, M8s, bias=M8b)
         else:
             h1 = h2 = None
-            z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2])); s2 = ops.row_stats(z2)
-            z3 = ops.gemm(z2, M8w, NT, bias=M8b, pro=Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3]))
+            z2 = ops.gemm(pre, M4w, NT, bias=M4b, pro=Pro(ACT_GELU, mu0, rs0, M1g, M1b, p1_, sd[2]), x3=x3); s2 = ops.row_stats(z2)
+            z3 = ops.gemm(z2, M8w, NT, bias=M8b, pro=Pro(ACT_GELU, s2[0], s2[1], M5g, M5b, p2_, sd[3]), x3=x3)
         if ops.rowdot_act_ok(z3, M10w):
             logit = ops.rowdot_act(z3, M10w, M10b, ACT_GELU)          # one-output Linear: a row dot product, not a GEMM
         else:

@@ -76,8 +76,9 @@ class Pro:
         self.drop_p, self.seed = float(drop_p), int(seed) & 0xFFFFFFFF
 
 
-def gemm(a, b, layout, bias=None, addend=None, out=None, accumulate=False, pro=None):
-    """C = pro(A)·B (+bias) (+addend) (+C).  NT: a[M,K] b[N,K]; NN: a[M,K] b[K,N]; TN: a[K,M] b[K,N]."""
+def gemm(a, b, layout, bias=None, addend=None, out=None, accumulate=False, pro=None, x3=False):
+    """C = pro(A)·B (+bias) (+addend) (+C).  NT: a[M,K] b[N,K]; NN: a[M,K] b[K,N]; TN: a[K,M] b[K,N].
+    x3=True: bf16x3 arithmetic on the fp32 operands (split while staged; see wf3d_gemm_t.x3); default exact fp32."""
     _need_cuda(a, b, bias, addend, out)
     a, b = _rows2d(a), _rows2d(b)
     if layout == NT:
@@ -125,6 +126,7 @@ def gemm(a, b, layout, bias=None, addend=None, out=None, accumulate=False, pro=N
         d.pro_mu, d.pro_rs, d.pro_gamma, d.pro_beta = _p(pro.mu), _p(pro.rs), _p(pro.gamma), _p(pro.beta)
         d.drop_p, d.drop_seed = pro.drop_p, pro.seed
     d.accumulate = 1 if accumulate else 0
+    d.x3 = 1 if x3 else 0
     lib = _lib.load()
     nb = lib.wf3d_gemm_ws_bytes(M, N, K, layout)
     ws = scratch(nb, a.device)
