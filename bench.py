@@ -327,7 +327,7 @@ def main():
                        "global_batch": B * world, "num_points": N, "max_vertices": V,
                        "parallelism": f"dp{world}", "algorithmic_gflop_per_cloud": total_fl / 1e9,
                        "arithmetic": ("fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate "
-                                      "(outputs within 1e-4 of the fp32 reference); heads and edge MLP on fp32 MFMA")
+                                      "(outputs within 1e-4 of the fp32 reference): per-point MLP, wide edge-MLP layers and per-vertex edge-head Linears; M=batch-row head Linears, K<=8 products and attention on fp32")
                        if split else "fp32 MFMA everywhere"},
             "roofline": roof,
         }

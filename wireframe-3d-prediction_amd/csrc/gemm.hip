@@ -126,9 +126,12 @@ __device__ __forceinline__ void store_tile(float* lds, int tid, const f32x4 (&v)
 
 // ---- staging, X3 mode: split fp32 registers into bf16 (hi, lo) pairs and write the k-contiguous "sx8" image
 // [rows][36 floats], each 32-B group = [8 x hi | 8 x lo] of 8 consecutive k — the image the bf16x3 MFMA loop reads.
-// A k-contiguous operand gives each thread 4 consecutive k of one row (two 8-B writes); a row-contiguous operand
-// gives 4 consecutive rows at one k, which is transposed here with 2-B writes.
+// A k-contiguous operand gives each thread 4 consecutive k of one row (two 8-B writes).  A row-contiguous operand
+// gives 4 consecutive rows at one k: it keeps its orientation — a bf16 plane [32 k][ROWS] of high parts followed by
+// one of low parts, k-row pitch ROWS*2 + 16 bytes (the four k-rows of a transposing read then sit on distinct
+// banks) — and is transposed by the fragment read (x3_tr_frag), not here.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int x3_ks(int rows) { return rows * 2 + 16; }       // bytes per k-row of a plane; 2 planes fit rows * LDK floats
 template <int ROWS, bool KC>
 __device__ __forceinline__ void store_tile_x3(float* lds, int tid, const f32x4 (&v)[ROWS / 32]) {
     constexpr int NV = ROWS / 32;
@@ -148,20 +151,31 @@ __device__ __forceinline__ void store_tile_x3(float* lds, int tid, const f32x4 (
     } else {
         constexpr int TPR = ROWS / 4;
         constexpr int KPP = 256 / TPR;
-        __bf16* l16 = reinterpret_cast<__bf16*>(lds);
+        constexpr int KS = x3_ks(ROWS);
+        char* lc = reinterpret_cast<char*>(lds);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int kk = tid / TPR + KPP * i;
+            bf16x4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const __bf16 hi = (__bf16)v[i][j];
-                const __bf16 lo = (__bf16)(v[i][j] - (float)hi);
-                __bf16* g = l16 + (((tid % TPR) * 4 + j) * LDK + (kk >> 3) * 8) * 2 + (kk & 7);
-                g[0] = hi;
-                g[8] = lo;
+                hi[j] = (__bf16)v[i][j];
+                lo[j] = (__bf16)(v[i][j] - (float)hi[j]);
             }
+            char* g = lc + (tid / TPR + KPP * i) * KS + (tid % TPR) * 8;
+            *reinterpret_cast<bf16x4*>(g) = hi;
+            *reinterpret_cast<bf16x4*>(g + BK * KS) = lo;
         }
     }
+}
+
+// X3 fragment of a row-contiguous operand: the 16 lanes of a group read a 4 k x 16 rows block of the plane with
+// ds_read_b64_tr_b16 (lane L addresses k-row L >> 2, rows 4 (L & 3) .. + 3) and each receives its own row's 4
+// k-values; two reads give the 8 consecutive k of the 32x32x16 operand.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 x3_tr_frag(const char* base, int off, int ks) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off + 4 * ks));
+    return __builtin_bit_cast(f32x4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // ---- fragment read: 4 consecutive-k values of one 32-row tile for this lane --
@@ -214,6 +228,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int h = lane >> 5, l31 = lane & 31;
+    const int l15 = lane & 15, hr = (lane >> 4) & 1;        // X3 transposing reads: lane within its 16-group, row half
 
     // per-thread staging base pointers (FAST path)
     const float* pa0 = A_KC ? p.A + (size_t)(m0 + (tid >> 3)) * p.lda + (tid & 7) * 4
@@ -338,15 +353,29 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
                 f32x4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const float* pr = As + ((wm * TM + i) * 32 + l31) * LDK + (2 * s2 + h) * 8;
-                    ah[i] = *reinterpret_cast<const f32x4*>(pr);
-                    al[i] = *reinterpret_cast<const f32x4*>(pr + 4);
+                    if (X3 && !A_KC) {
+                        constexpr int KS = x3_ks(BM);
+                        const int off = (16 * s2 + 8 * h + (l15 >> 2)) * KS + ((wm * TM + i) * 32 + 16 * hr + (l15 & 3) * 4) * 2;
+                        ah[i] = x3_tr_frag(reinterpret_cast<const char*>(As), off, KS);
+                        al[i] = x3_tr_frag(reinterpret_cast<const char*>(As), off + BK * KS, KS);
+                    } else {
+                        const float* pr = As + ((wm * TM + i) * 32 + l31) * LDK + (2 * s2 + h) * 8;
+                        ah[i] = *reinterpret_cast<const f32x4*>(pr);
+                        al[i] = *reinterpret_cast<const f32x4*>(pr + 4);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const float* pr = Bs + ((wn * TN + j) * 32 + l31) * LDK + (2 * s2 + h) * 8;
-                    bh[j] = *reinterpret_cast<const f32x4*>(pr);
-                    bl[j] = *reinterpret_cast<const f32x4*>(pr + 4);
+                    if (X3 && !B_KC) {
+                        constexpr int KS = x3_ks(BN);
+                        const int off = (16 * s2 + 8 * h + (l15 >> 2)) * KS + ((wn * TN + j) * 32 + 16 * hr + (l15 & 3) * 4) * 2;
+                        bh[j] = x3_tr_frag(reinterpret_cast<const char*>(Bs), off, KS);
+                        bl[j] = x3_tr_frag(reinterpret_cast<const char*>(Bs), off + BK * KS, KS);
+                    } else {
+                        const float* pr = Bs + ((wn * TN + j) * 32 + l31) * LDK + (2 * s2 + h) * 8;
+                        bh[j] = *reinterpret_cast<const f32x4*>(pr);
+                        bl[j] = *reinterpret_cast<const f32x4*>(pr + 4);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)

@@ -29,12 +29,12 @@ def _saved(ctx):
     return ctx.saved
 
 
-def _lin_bwd(dz, a, W, pro_a, need_da=True):
+def _lin_bwd(dz, a, W, pro_a, need_da=True, x3=False):
     """Linear backward pieces for z = pro(a)·W^T + b given dz:
     dW = dz^T·pro(a) (TN, prologue re-applied to the stored pre-activation),
     d pro(a) = dz·W (NN)."""
-    dW = ops.gemm(dz, a, TN, pro=pro_a)
-    da = ops.gemm(dz, W, NN) if need_da else None
+    dW = ops.gemm(dz, a, TN, pro=pro_a, x3=x3)
+    da = ops.gemm(dz, W, NN, x3=x3) if need_da else None
     return dW, da
 
 
@@ -407,10 +407,8 @@ class EdgeFn(torch.autograd.Function):
         pf_, pa_, p1_, p2_ = (float(x) for x in drop_ps)   # vertex_proj.5, attention, edge_mlp.3, edge_mlp.7
         cv = ops.edge_gather_verts(verts, meta)
         za = ops.gemm(cv, P0w, NT, bias=P0b); sa = ops.row_stats(za)
-        # per-vertex Linears (sum-of-counts rows): in bf16x3 mode the fp32 operands of the forward (NT) products are
-        # split inside the GEMM's staging pass (x3).  The K = 3 coordinate products and the backward's NN / TN
-        # products stay on fp32 MFMA: their row-contiguous operands would have to be transposed while staged, which
-        # measured slower than the fp32 loop it replaces (26 -> 31 us, 48 -> 70 us per launch at cfg2).
+        # per-vertex Linears (sum-of-counts rows): in bf16x3 mode the fp32 operands are split inside the GEMM's
+        # staging pass (x3), forward and backward; the K = 3 coordinate products stay exact fp32
         x3 = precision == "bf16x3"
         zb = ops.gemm(za, P3w, NT, bias=P3b, pro=Pro(ACT_GELU, sa[0], sa[1], P1g, P1b), x3=x3); sb = ops.row_stats(zb)
         f = ops.ln_act_apply(zb, sb[0], sb[1], P4g, P4b, ACT_NONE, drop_p=pf_, seed=sd[0])
@@ -447,7 +445,7 @@ class EdgeFn(torch.autograd.Function):
             logit = ops.gemm(z3, M10w, NT, bias=M10b, pro=Pro(ACT_GELU))
         probs = ops.edge_prob_fwd(logit, meta)
         ctx.params, ctx.cfg = params, (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
-        ctx.split = split
+        ctx.split, ctx.x3 = split, x3
         ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2)
         ctx.save_for_backward(probs)
         return probs
@@ -461,6 +459,7 @@ class EdgeFn(torch.autograd.Function):
         cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2 = _saved(ctx)
         (probs,) = ctx.saved_tensors
         G = [None] * len(params)
+        x3 = ctx.x3
         dlogit = ops.edge_prob_bwd(probs, dprobs.contiguous(), meta)                      # [Re,1]
         G[23] = ops.colsum(dlogit)
         fused_tail = ops.rowdot_act_ok(z3, M10w)
@@ -489,7 +488,7 @@ class EdgeFn(torch.autograd.Function):
                 G[20] = _wgrad_tn(dz3_s, h2)
             else:
                 G[20] = (ops.gemm_split(ops.split_transpose(dz3_s, in_sx8=True), ops.split_transpose(z2, p2)) if tsplit
-                         else ops.gemm(dz3, z2, TN, pro=p2))
+                         else ops.gemm(dz3, z2, TN, pro=p2, x3=x3))
             dh2 = ops.gemm_split(dz3_s, ctx.wT[1])
             del dz3, dz3_s
             dz2_s = torch.empty_like(dh2)
@@ -500,7 +499,7 @@ class EdgeFn(torch.autograd.Function):
                 G[16] = _wgrad_tn(dz2_s, h1)
             else:
                 G[16] = (ops.gemm_split(ops.split_transpose(dz2_s, in_sx8=True), ops.split_transpose(pre, p1)) if tsplit
-                         else ops.gemm(dz2, pre, TN, pro=p1))
+                         else ops.gemm(dz2, pre, TN, pro=p1, x3=x3))
             dh1 = ops.gemm_split(dz2_s, ctx.wT[0])
             del dz2, dz2_s
         else:
@@ -508,9 +507,9 @@ class EdgeFn(torch.autograd.Function):
                 dz3, G[22], G[21] = ops.rowdot_act_bwd(z3, dlogit, M10w, ACT_GELU)
             else:
                 dz3, _, _, G[21] = ops.ln_act_bwd(dh3, z3, None, None, None, None, ACT_GELU, inplace=True)
-            G[20], dh2 = _lin_bwd(dz3, z2, M8w, p2)
+            G[20], dh2 = _lin_bwd(dz3, z2, M8w, p2, x3=x3)
             dz2, G[18], G[19], G[17] = ops.ln_act_bwd(dh2, z2, s2[0], s2[1], M5g, M5b, ACT_GELU, p2_, sd[3], inplace=True)
-            G[16], dh1 = _lin_bwd(dz2, pre, M4w, p1)
+            G[16], dh1 = _lin_bwd(dz2, pre, M4w, p1, x3=x3)
         # LN/GELU backward of the first edge layer; the same pass yields the gradient of its distance-weight column
         dpre, G[14], G[15], wsum = ops.ln_act_bwd_wsum(dh1, pre, delta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], inplace=True)
         # split first layer backward
@@ -518,26 +517,26 @@ class EdgeFn(torch.autograd.Function):
         dW0[:, 2 * H + 6].copy_(wsum)
         dPa, dPb, dcv = ops.edge_pair_bwd(dpre, delta, cv, M0w, meta)
         G[13] = ops.colsum(dPa)
-        ops.gemm(dPa, Fm, TN, out=dW0[:, :H])
-        ops.gemm(dPb, Fm, TN, out=dW0[:, H:2 * H])
+        ops.gemm(dPa, Fm, TN, out=dW0[:, :H], x3=x3)
+        ops.gemm(dPb, Fm, TN, out=dW0[:, H:2 * H], x3=x3)
         ops.gemm(dPa, cv, TN, out=dW0[:, 2 * H:2 * H + 3])
         ops.gemm(dPb, cv, TN, out=dW0[:, 2 * H + 3:2 * H + 6])
         G[12] = dW0
         Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + 3], M0w[:, 2 * H + 3:2 * H + 6]
-        dF = ops.gemm(dPa, Wa, NN)
-        ops.gemm(dPb, Wb, NN, out=dF, accumulate=True)
+        dF = ops.gemm(dPa, Wa, NN, x3=x3)
+        ops.gemm(dPb, Wb, NN, out=dF, accumulate=True, x3=x3)
         ops.gemm(dPa, Wc, NN, out=dcv, accumulate=True)
         ops.gemm(dPb, Wd, NN, out=dcv, accumulate=True)
         # F = f + out_proj(ctx)
         G[11] = ops.colsum(dF)
-        G[10], dcx = _lin_bwd(dF, cx, Ow, None)
+        G[10], dcx = _lin_bwd(dF, cx, Ow, None, x3=x3)
         dqkv = ops.attn_bwd(qkv, dcx, cx, lse, meta, H, heads, pa_, sd[1])
         G[9] = ops.colsum(dqkv)
-        G[8] = ops.gemm(dqkv, f, TN)
-        df = ops.gemm(dqkv, Aw, NN, addend=dF)
+        G[8] = ops.gemm(dqkv, f, TN, x3=x3)
+        df = ops.gemm(dqkv, Aw, NN, addend=dF, x3=x3)
         # f = drop(LN(zb))
         dzb, G[6], G[7], G[5] = ops.ln_act_bwd(df, zb, sb[0], sb[1], P4g, P4b, ACT_NONE, pf_, sd[0], inplace=True)
-        G[4], dha = _lin_bwd(dzb, za, P3w, Pro(ACT_GELU, sa[0], sa[1], P1g, P1b))
+        G[4], dha = _lin_bwd(dzb, za, P3w, Pro(ACT_GELU, sa[0], sa[1], P1g, P1b), x3=x3)
         dza, G[2], G[3], G[1] = ops.ln_act_bwd(dha, za, sa[0], sa[1], P1g, P1b, ACT_GELU, inplace=True)
         G[0] = ops.gemm(dza, cv, TN)
         ops.gemm(dza, P0w, NN, out=dcv, accumulate=True)
