@@ -905,8 +905,15 @@ void plan_tn(int Mo, int No, int K, int& ksplit, int& kt_per) {
     if (tiles >= 256 || ktotal < 8) return;
     // one workgroup per CU either way; the big tile runs one full wave of 256 workgroups
     int want = (int)(((big ? 256 : 512) + tiles - 1) / tiles);
-    int ks = want < ktotal / 4 ? want : ktotal / 4;
-    if (ks > 64) ks = 64;
+    // One or two output tiles (the edge MLP's 128 x 256 and 256 x 512 weights over ~10^5 - 10^6 edge rows) are a streaming
+    // reduction over K: they get a K range per CU (up to 256 slabs) as long as a range keeps >= 8 slices; more tiles
+    // keep the 64-range cap that bounds the slab traffic (with 64 ranges the 128 x 256 wgrad of cfg5 ran on 64 CUs
+    // at 2.0 TB/s, the 256 x 512 one on half the chip).
+    const bool few = tiles <= 4;
+    int ks = want < ktotal / (few ? 8 : 4) ? want : ktotal / (few ? 8 : 4);
+    const int cap = few ? 256 : 64;
+    if (ks > cap) ks = cap;
+    if (few && ks >= 8) ks &= ~7;                 // multiples of 8: the XCD-mapped launch order applies
     if (ks < 2) return;
     kt_per = wf3d_cdiv(ktotal, ks);
     ksplit = wf3d_cdiv(ktotal, kt_per);

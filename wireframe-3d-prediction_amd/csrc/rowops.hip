@@ -118,15 +118,43 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
         for (int i = 0; i < NS; ++i) a_dw[k][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float invD = 1.0f / (float)D;
     const int iters = (R + gridDim.x * RPI - 1) / (gridDim.x * RPI);
+    // the row of iteration it + 1 is loaded while row it is reduced and written: one barrier per row otherwise
+    // leaves a workgroup with nothing in flight between its rows
+    f32x4 zn[NS], dn[NS];
+    float mn = 0.f, rn = 1.f, xkn[KX > 0 ? KX : 1];
+    auto load_row = [&](int it) {
+        const int row = (it * gridDim.x + blockIdx.x) * RPI + wrow;
+        const bool live = it < iters && row < R;
+        mn = (has_ln && live) ? mu[row] : 0.f;
+        rn = (has_ln && live) ? rs[row] : 1.f;
+        if (KX > 0) {
+#pragma unroll
+            for (int k = 0; k < KX; ++k) xkn[k] = (live && k < kx) ? x0[(size_t)row * ldx + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = cbeg + lane * 4 + 256 * i;
+            zn[i] = dn[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (live && c < cend) {
+                zn[i] = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
+                dn[i] = *reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c);
+            }
+        }
+    };
+    load_row(0);
     for (int it = 0; it < iters; ++it) {
         const int row = (it * gridDim.x + blockIdx.x) * RPI + wrow;
         const bool live = row < R;
-        const float m = (has_ln && live) ? mu[row] : 0.f, r = (has_ln && live) ? rs[row] : 1.f;
+        const float m = mn, r = rn;
         float xk[KX > 0 ? KX : 1];
         if (KX > 0) {
 #pragma unroll
-            for (int k = 0; k < KX; ++k) xk[k] = (live && k < kx) ? x0[(size_t)row * ldx + k] : 0.f;
+            for (int k = 0; k < KX; ++k) xk[k] = xkn[k];
         }
+        f32x4 zc[NS], dc[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { zc[i] = zn[i]; dc[i] = dn[i]; }
+        load_row(it + 1);
         f32x4 xh[NS], gg[NS];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -134,8 +162,8 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
             const int c = cbeg + lane * 4 + 256 * i;
             xh[i] = gg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (live && c < cend) {
-                const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
-                const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c);
+                const f32x4 zv = zc[i];
+                const f32x4 dv = dc[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float x = (zv[j] - m) * r;

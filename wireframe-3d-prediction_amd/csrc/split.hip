@@ -97,52 +97,70 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
                                                        int act, float eps, uint32_t seed, uint32_t thresh, float dscale,
                                                        float* __restrict__ mu, float* __restrict__ rs,
                                                        float* __restrict__ h_sx8) {
+    // persistent: a lane group walks rows first, first + step, ... with its slice of gamma / beta in registers and
+    // the next row's z already requested while this row is reduced, normalised and stored
+    constexpr int RPB = 256 / LPR;
     const int lane = threadIdx.x & (LPR - 1);
-    const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-    if (row >= R) return;                     // whole rows (aligned lane groups) leave together: the shuffles below stay inside a row
-    const float* p = z + (size_t)row * D;
-    float v[NS][8];
-    float s = 0.f;
+    const int rstep = gridDim.x * RPB;
+    float gm[NS][8], bt[NS][8];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = lane * 8 + 512 * i;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-        if (c < D) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[i][j] = a[j]; v[i][4 + j] = b[j]; s += a[j] + b[j]; }
-        }
-    }
-    const float mean = row_sum<LPR>(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int c = lane * 8 + 512 * i;
-        if (c < D)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-    }
-    const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)D + eps);
-    if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int c = lane * 8 + 512 * i;
+        for (int j = 0; j < 8; ++j) { gm[i][j] = 1.f; bt[i][j] = 0.f; }
         if (c < D) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
-            float o[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * g0[j] + b0[j]);
-                o[4 + j] = wf3d_act_rt(act, (v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
-            }
-            if (thresh) {
+            for (int j = 0; j < 4; ++j) { gm[i][j] = g0[j]; gm[i][4 + j] = g1[j]; bt[i][j] = b0[j]; bt[i][4 + j] = b1[j]; }
+        }
+    }
+    f32x4 na[NS], nb[NS];
+    auto load_row = [&](int row) {
+        const float* p = z + (size_t)min(row, R - 1) * D;          // clamped: a row >= R is loaded but never used
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = wf3d_keep(seed, (uint32_t)row, (uint32_t)(c + j), thresh) ? o[j] * dscale : 0.f;
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 8 + 512 * i;
+            na[i] = nb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < D) { na[i] = *reinterpret_cast<const f32x4*>(p + c); nb[i] = *reinterpret_cast<const f32x4*>(p + c + 4); }
+        }
+    };
+    int row = blockIdx.x * RPB + threadIdx.x / LPR;
+    load_row(row);
+    // whole rows (aligned lane groups) leave together: the shuffles below stay inside a row
+    for (; row < R; row += rstep) {
+        float v[NS][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[i][j] = na[i][j]; v[i][4 + j] = nb[i][j]; s += na[i][j] + nb[i][j]; }
+        load_row(row + rstep);
+        const float mean = row_sum<LPR>(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < D)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+        const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)D + eps);
+        if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < D) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
+                if (thresh) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = wf3d_keep(seed, (uint32_t)row, (uint32_t)(c + j), thresh) ? o[j] * dscale : 0.f;
+                }
+                store_sx8(h_sx8 + (size_t)row * D + c, o);
             }
-            store_sx8(h_sx8 + (size_t)row * D + c, o);
         }
     }
 }
@@ -368,11 +386,16 @@ extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, co
                ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_ln_prep: pointers must be 16-byte aligned");
     const int ns = wf3d_cdiv(D, 512);
     hipStream_t st = (hipStream_t)stream;
+    // persistent grid: a few workgroups per CU (WF3D_LNPREP_WGS overrides, for sweeps)
+    static const int lp_wgs = [] { const char* e = getenv("WF3D_LNPREP_WGS"); return e ? atoi(e) : 4096; }();
+    const int rpb = D <= 256 ? 8 : 4;
+    int blocks = wf3d_cdiv(R, rpb);
+    if (blocks > lp_wgs) blocks = lp_wgs;
 #define WF3D_LP(NS_)                                                                                              \
-    hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(wf3d_cdiv(R, 4)), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
+    hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(blocks), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
                        drop_seed, thresh, dscale, mu, rs, (float*)h_sx8)
     if (D <= 256)      // two rows per wave
-        hipLaunchKernelGGL((ln_prep_kernel<1, 32>), dim3(wf3d_cdiv(R, 8)), dim3(256), 0, st, z, R, D, gamma, beta, act, eps,
+        hipLaunchKernelGGL((ln_prep_kernel<1, 32>), dim3(blocks), dim3(256), 0, st, z, R, D, gamma, beta, act, eps,
                            drop_seed, thresh, dscale, mu, rs, (float*)h_sx8);
     else if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
 #undef WF3D_LP
