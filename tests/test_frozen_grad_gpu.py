@@ -108,3 +108,27 @@ def test_frozen_gradients_bf16x3_measured(B, N, V, counts):
         assert a < TOL and b < TOL, (k, a, b)
     bad = [(n, e) for n, e in errs.items() if not e <= 5e-4]
     assert not bad, bad
+
+
+# Shape sweep: the same check over the corners of the shape space — a single point, a single edge, odd point
+# counts, ragged vertex counts down to 2, more clouds than the 32-row head kernels take (generic GEMM path),
+# max_vertices = 64 with five clouds.  Every parameter gradient element-wise, both arithmetic modes.
+SWEEP = [
+    (1, 1, 2, [2]),
+    (1, 33, 3, [3]),
+    (2, 77, 5, [2, 5]),
+    (4, 24, 17, [17, 2, 9, 3]),
+    (5, 16, 64, [64, 33, 2, 7, 50]),
+    (33, 4, 4, [4, 2, 3] * 11),
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("B,N,V,counts", SWEEP)
+def test_frozen_gradients_shape_sweep(precision, B, N, V, counts):
+    fwd, errs, seed = _run(precision, B, N, V, counts)
+    for k, (a, b) in fwd.items():
+        assert a < TOL and b < TOL, (k, a, b)
+    tol = TOL if precision == "fp32" else 5e-4
+    bad = [(n, e) for n, e in errs.items() if not e <= tol]
+    assert not bad, (seed, bad)
