@@ -11,7 +11,7 @@ while [ $# -gt 1 ]; do
   tag=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c $src -o build/${base}_$tag.o
   objs=""
-  for o in capi gemm rowops pool attn edge split gemm_split attn_mfma loss skinny optim; do
+  for o in capi gemm rowops pool attn edge split gemm_split attn_mfma loss skinny optim cloud evalpost; do
     if [ "$o" != "$base" ]; then objs="$objs build/$o.o"; fi
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwf3d_$tag.so $objs build/${base}_$tag.o

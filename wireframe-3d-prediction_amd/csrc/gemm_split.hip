@@ -22,7 +22,7 @@
 #include "wf3d_common.h"
 
 #ifndef WF3D_ABLATE
-#define WF3D_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no LDS fragment reads
+#define WF3D_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no LDS fragment reads, 4 = wgrad kernel with plain b128 fragment reads (wrong values)
 #endif
 
 #ifndef WF3D_DMA_SCHED
@@ -536,11 +536,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
         const char* Ac = reinterpret_cast<const char*>(As);
         const char* Bc = reinterpret_cast<const char*>(Bs);
         auto rdA = [&](int i, bool lo) -> f32x4 {
-            if (TN) return tr_frag16(Ac, lo ? (a_tn[i] ^ 16) : a_tn[i]);
+            if (TN && WF3D_ABLATE != 4) return tr_frag16(Ac, lo ? (a_tn[i] ^ 16) : a_tn[i]);
             return *reinterpret_cast<const f32x4*>(As + a_row + i * 16 * SBK + (lo ? c_lo : c_hi));
         };
         auto rdB = [&](int j, bool lo) -> f32x4 {
-            if (TN) return tr_frag16(Bc, lo ? (b_tn[j] ^ 16) : b_tn[j]);
+            if (TN && WF3D_ABLATE != 4) return tr_frag16(Bc, lo ? (b_tn[j] ^ 16) : b_tn[j]);
             return *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + (lo ? c_lo : c_hi));
         };
         f32x4 bh[4], bl[4], ah, al, ahn, aln;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
                 aln = rdA(i + 1, true);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (i < 4) {          // B(kt+1) first, A(kt+2) last: the slice-end wait skips exactly the 4 youngest
+            if (i < 4 && WF3D_ABLATE != 1) {          // B(kt+1) first, A(kt+2) last: the slice-end wait skips exactly the 4 youngest
                 if (i < 2) { dma16_asm(bsrc[2 * i] + kb, dB + (2 * i) * 8 * SBK);         dma16_asm(bsrc[2 * i + 1] + kb, dB + (2 * i + 1) * 8 * SBK); }
                 else       { dma16_asm(asrc[2 * i - 4] + ka, dA + (2 * i - 4) * 8 * SBK); dma16_asm(asrc[2 * i - 3] + ka, dA + (2 * i - 3) * 8 * SBK); }
             }
