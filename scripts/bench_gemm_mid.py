@@ -42,5 +42,21 @@ def main():
                 print(f"{name:6} {M:6d} {N:5d} {K:5d}  {t0:7.1f}  {t1:7.1f}")
 
 
+def wgrads():
+    """dW[M, N] = dz^T a over K = sum-of-vertex-count rows (TN): small outputs, split-K + combine launch included."""
+    dev = torch.device("cuda:0")
+    print(f"{'wgrad':6} {'M':>6} {'N':>5} {'K':>5}  fp32 us   x3 us")
+    for K in (2048, 8192):
+        for (M, N) in ((512, 512), (1536, 512), (512, 256), (512, 3)):
+            a, b = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
+            out = torch.empty(M, N, device=dev)
+            t0 = timed(lambda: ops.gemm(a, b, ops.TN, out=out))
+            t1 = timed(lambda: ops.gemm(a, b, ops.TN, out=out, x3=True))
+            print(f"{'TN':6} {M:6d} {N:5d} {K:5d}  {t0:7.1f}  {t1:7.1f}")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
+        wgrads()
+    else:
+        main()

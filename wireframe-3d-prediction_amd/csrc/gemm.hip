@@ -516,6 +516,44 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmParams p) {
     }
 }
 
+// The same combine for many slabs (few output tiles, up to 256 K ranges): a wave owns 16 consecutive outputs, lane =
+// (slab lane 0..15, float4 0..3) walks slabs sl, sl + 16, ... with four loads in flight, the 16 partial sums meet in
+// a fixed shuffle tree (deterministic).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_wide(const GemmParams p) {
+    const size_t total = (size_t)p.M * p.N;
+    const int lane = threadIdx.x & 63, sl = lane >> 2, q = lane & 3;
+    const size_t idx = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + q * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool live = idx < total;
+    if (live) {
+        const float* base = p.slab + idx;
+        for (int z = sl; z < p.ksplit; z += 64) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (size_t)z * total);
+            const f32x4 v1 = z + 16 < p.ksplit ? *reinterpret_cast<const f32x4*>(base + (size_t)(z + 16) * total) : zero;
+            const f32x4 v2 = z + 32 < p.ksplit ? *reinterpret_cast<const f32x4*>(base + (size_t)(z + 32) * total) : zero;
+            const f32x4 v3 = z + 48 < p.ksplit ? *reinterpret_cast<const f32x4*>(base + (size_t)(z + 48) * total) : zero;
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (live && sl == 0) {
+        const int row = (int)(idx / p.N), col = (int)(idx % p.N);          // N % 4 == 0: the float4 stays inside its row
+        float* c = p.C + (size_t)row * p.ldc + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e];
+            if (p.bias) v += p.bias[col + e];
+            if (p.addend) v += p.addend[(size_t)row * p.ld_addend + col + e];
+            if (p.accumulate) v += c[e];
+            c[e] = v;
+        }
+    }
+}
+
 struct SplitPlan { int ksplit, kt_per; };
 
 SplitPlan plan_split(int M, int N, int K, int bm, int bn) {
@@ -560,9 +598,19 @@ void launch_tile(const GemmParams& p, int kind, bool x3, hipStream_t st) {
 }
 
 template <int ACT, bool PRO>
-void launch_tn(const GemmParams& p, bool x3, hipStream_t st) {
-    if (x3) launch<2, 2, 2, 2, false, false, ACT, PRO, true>(p, st);
-    else    launch<2, 2, 2, 2, false, false, ACT, PRO>(p, st);
+void launch_tn(const GemmParams& p, int kind, bool x3, hipStream_t st) {
+    if (kind == 2) { if (x3) launch<2, 2, 1, 1, false, false, ACT, PRO, true>(p, st); else launch<2, 2, 1, 1, false, false, ACT, PRO>(p, st); }
+    else           { if (x3) launch<2, 2, 2, 2, false, false, ACT, PRO, true>(p, st); else launch<2, 2, 2, 2, false, false, ACT, PRO>(p, st); }
+}
+
+// wgrad of a per-vertex Linear (a [512, 512]-class output over a few thousand rows): 128 x 128 tiles leave 16 of them,
+// each cut into 16 K ranges of 4 slices; 64 x 64 tiles give 64, cut 8 ways: 22 -> 16 us at [512, 512] x 2048 rows,
+// 38 -> 29 us at [1536, 512] (scripts/bench_gemm_mid.py wgrad).  Long reductions over the larger outputs keep the
+// big tile (77 vs 81 us at [1536, 512] x 8192).  WF3D_TN_MID=0 switches it off.
+inline bool tn_mid(int M, int N, int K) {
+    static const int on = [] { const char* e = getenv("WF3D_TN_MID"); return e ? atoi(e) : 1; }();
+    const long t128 = (long)wf3d_cdiv(M, 128) * wf3d_cdiv(N, 128);
+    return on && M > 64 && N > 64 && t128 < 64 && (K <= 4096 || t128 <= 16);
 }
 
 }  // namespace
@@ -570,7 +618,7 @@ void launch_tn(const GemmParams& p, bool x3, hipStream_t st) {
 extern "C" size_t wf3d_gemm_ws_bytes(int M, int N, int K, int layout) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const bool small = layout != WF3D_TN && small_m(M);
-    const bool mid = layout != WF3D_TN && !small && mid_tile(M, N, K);
+    const bool mid = layout != WF3D_TN ? (!small && mid_tile(M, N, K)) : tn_mid(M, N, K);
     SplitPlan s = plan_split(M, N, K, small ? 32 : (mid ? 64 : 128), mid ? 64 : 128);
     return s.ksplit > 1 ? (size_t)s.ksplit * M * N * sizeof(float) : 0;
 }
@@ -611,7 +659,7 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     p.vecP = !p.has_affine || (((uintptr_t)d->pro_gamma % 16 == 0) && ((uintptr_t)d->pro_beta % 16 == 0));
 
     const bool small = d->layout != WF3D_TN && small_m(d->M);
-    const bool mid = d->layout != WF3D_TN && !small && mid_tile(d->M, d->N, d->K);
+    const bool mid = d->layout != WF3D_TN ? (!small && mid_tile(d->M, d->N, d->K)) : tn_mid(d->M, d->N, d->K);
     const int kind = small ? 1 : (mid ? 2 : 0);
     const int bm = small ? 32 : (mid ? 64 : 128), bn = mid ? 64 : 128;
     p.nbm = wf3d_cdiv(d->M, bm);
@@ -634,17 +682,21 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     } else if (d->layout == WF3D_NN) {
         launch_tile<true, false, 0, false>(p, kind, x3, st);
     } else {
-        if (!pro)                         launch_tn<0, false>(p, x3, st);
-        else if (act == WF3D_ACT_RELU)    launch_tn<WF3D_ACT_RELU, true>(p, x3, st);
-        else if (act == WF3D_ACT_GELU)    launch_tn<WF3D_ACT_GELU, true>(p, x3, st);
-        else                              launch_tn<WF3D_ACT_NONE, true>(p, x3, st);
+        if (!pro)                         launch_tn<0, false>(p, kind, x3, st);
+        else if (act == WF3D_ACT_RELU)    launch_tn<WF3D_ACT_RELU, true>(p, kind, x3, st);
+        else if (act == WF3D_ACT_GELU)    launch_tn<WF3D_ACT_GELU, true>(p, kind, x3, st);
+        else                              launch_tn<WF3D_ACT_NONE, true>(p, kind, x3, st);
     }
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
         const size_t total = (size_t)p.M * p.N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        if (p.ksplit > 16 && p.N % 4 == 0 && ((uintptr_t)p.slab % 16 == 0)) {
+            hipLaunchKernelGGL(gemm_splitk_reduce_wide, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, p);
+        } else {
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        }
         WF3D_LAUNCH_CHECK();
     }
     return WF3D_OK;

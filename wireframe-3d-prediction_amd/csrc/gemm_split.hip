@@ -791,6 +791,55 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) 
     }
 }
 
+// The same fold for many slabs (the few-tile wgrads split K up to 256 ways): a serial walk over the slabs is one
+// dependent 4-byte load per slab per thread (126 slabs of 128 KB took 55 us).  Here a wave owns 16 consecutive
+// outputs; lane = (slab lane 0..15, float4 0..3) walks slabs sl, sl + 16, ... four loads in flight, and the 16
+// partial sums meet in a fixed shuffle tree — the result does not depend on timing.
+__global__ __launch_bounds__(256) void split_reduce_wide_kernel(const SplitParams p) {
+    const size_t total = (size_t)p.M * p.N;
+    const int lane = threadIdx.x & 63, sl = lane >> 2, q = lane & 3;
+    const size_t idx = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + q * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool live = idx < total;
+    if (live) {
+        const float* base = p.slab + idx;
+        for (int z = sl; z < p.ksplit; z += 64) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (size_t)z * total);
+            const f32x4 v1 = z + 16 < p.ksplit ? *reinterpret_cast<const f32x4*>(base + (size_t)(z + 16) * total) : zero;
+            const f32x4 v2 = z + 32 < p.ksplit ? *reinterpret_cast<const f32x4*>(base + (size_t)(z + 32) * total) : zero;
+            const f32x4 v3 = z + 48 < p.ksplit ? *reinterpret_cast<const f32x4*>(base + (size_t)(z + 48) * total) : zero;
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (live && sl == 0) {
+        const int row = (int)(idx / p.N), col = (int)(idx % p.N);          // N % 4 == 0: the float4 stays inside its row
+        float* c = p.C + (size_t)row * p.ldc + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e];
+            if (p.bias) v += p.bias[col + e];
+            if (p.accumulate) v += c[e];
+            c[e] = v;
+        }
+    }
+}
+
+void launch_split_reduce(const SplitParams& p, hipStream_t st) {
+    const size_t total = (size_t)p.M * p.N;
+    if (p.ksplit > 16 && p.N % 4 == 0 && ((uintptr_t)p.slab % 16 == 0)) {
+        hipLaunchKernelGGL(split_reduce_wide_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, p);
+        return;
+    }
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+}
+
 // Kernel choice.  WF3D_SPLIT_DMA forces one: 2 = 128x128 2-stage, 3 = 256x128 3-stage,
 // 4 = 256x256 2-stage (32x32x16 MFMA), 5 = 256x256 4-stage k16 register-pipelined, 6 = 256x256
 // 2-stage on 16x16x32 MFMA, 7 = 128x128 two-workgroups-per-CU on 16x16x32 (measured 20 % slower than 6).  Default (unset): 6 when the output has >= 512 such tiles (the tall
@@ -876,10 +925,7 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     }
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
-        const size_t total = (size_t)M * N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        launch_split_reduce(p, st);
         WF3D_LAUNCH_CHECK();
     }
     return WF3D_OK;
@@ -952,10 +998,7 @@ extern "C" int wf3d_gemm_split_tn(const void* A_sx8, const void* B_sx8, float* C
     else     hipLaunchKernelGGL(gemm_split_tn_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     WF3D_LAUNCH_CHECK();
     if (p.ksplit > 1) {
-        const size_t total = (size_t)Mo * No;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        launch_split_reduce(p, st);
         WF3D_LAUNCH_CHECK();
     }
     return WF3D_OK;
