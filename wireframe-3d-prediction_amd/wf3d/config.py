@@ -25,3 +25,9 @@ def set_precision(p):
     if p not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")
     _precision = p
+
+
+# Backward of the edge head: weight / bias gradients that nothing downstream reads ("leaves") are issued on a second
+# HIP stream next to the dgrad chain (these launches are 15-60 us kernels that fill a fraction of the chip; in one
+# stream each also pays the drain of its predecessor).  WF3D_SIDE_STREAM=0 keeps everything on the current stream.
+SIDE_STREAM = os.environ.get("WF3D_SIDE_STREAM", "1") != "0"
