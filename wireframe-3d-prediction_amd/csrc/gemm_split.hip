@@ -25,6 +25,10 @@
 #define WF3D_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no LDS fragment reads, 4 = wgrad kernel with plain b128 fragment reads (wrong values)
 #endif
 
+#ifndef WF3D_NT_STORE
+#define WF3D_NT_STORE 0    // persistent kernel: 1 = non-temporal C stores (experiment)
+#endif
+
 #ifndef WF3D_DMA_SCHED
 #define WF3D_DMA_SCHED 0   // 256x256 kernel: 0 = DMA pieces spread over the slice, 1 = over its first half, 2 = bunched at the top
 #endif
@@ -763,9 +767,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
                     for (int e = 0; e < 4; ++e) v[e] += p.bias[col + e];
                 }
                 float* c = p.C + (size_t)row * p.ldc + col;
+                if (WF3D_ABLATE == 3 && v[0] != 1234.5f) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }       // timing-only: no C stores
                 if (vec) {
                     if (p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
-                    *reinterpret_cast<f32x4*>(c) = v;
+                    if (WF3D_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(c));
+                    else *reinterpret_cast<f32x4*>(c) = v;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) c[e] = p.accumulate ? c[e] + v[e] : v[e];
