@@ -415,3 +415,36 @@ def test_second_backward_raises_a_clear_error():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         loss.backward()
+
+
+def test_inplace_parameter_update_between_forward_and_backward_is_reported():
+    """The stages keep their parameters as plain references; an optimizer step (or any in-place write) between the
+    forward and its backward must raise, as autograd does for saved tensors — not differentiate against new values."""
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    from wf3d.optim import ClipAdam
+    torch.manual_seed(3)
+    model = PointCloudToWireframe(8, 6).to(dev()).set_dropout(0.0)
+    model.train()
+    x = torch.randn(2, 40, 8, device=dev())
+    counts = torch.tensor([6, 3], device=dev())
+    out = model(x, counts)
+    with torch.no_grad():
+        model.edge_predictor.edge_mlp[0].weight.mul_(1.0)            # in-place write, values unchanged
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out["edge_probs"].sum().backward()
+    # the fused optimizer writes through raw pointers and must bump the counters itself
+    out = model(x, counts)
+    (out["edge_probs"].sum() + out["vertices"].sum() + out["existence_probabilities"].sum()).backward()
+    opt = ClipAdam(model.parameters(), lr=1e-3, max_norm=1.0)
+    out2 = model(x, counts)
+    opt.step()
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out2["vertices"].sum().backward()
+
+
+def test_input_cloud_gradient_is_refused_not_silently_none():
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    model = PointCloudToWireframe(8, 4).to(dev()).set_dropout(0.0)
+    x = torch.randn(1, 16, 8, device=dev(), requires_grad=True)
+    with pytest.raises(NotImplementedError, match="input cloud"):
+        model(x, torch.tensor([4], device=dev()))

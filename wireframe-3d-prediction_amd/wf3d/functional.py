@@ -29,6 +29,23 @@ def _saved(ctx):
     return ctx.saved
 
 
+def _keep_params(ctx, params):
+    """Parameters are kept as plain attributes (save_for_backward would forbid the views the stages take of them);
+    their version counters are recorded so that an in-place update between forward and backward is reported the way
+    autograd reports it for saved tensors, instead of silently producing gradients against the new values."""
+    ctx.params = params
+    ctx.param_versions = [None if p is None else p._version for p in params]
+
+
+def _params(ctx):
+    for i, (p, v) in enumerate(zip(ctx.params, ctx.param_versions)):
+        if p is not None and p._version != v:
+            raise RuntimeError(f"wf3d: parameter {i} of this stage (shape {tuple(p.shape)}) was modified in place after the "
+                               f"forward that is being differentiated (version {p._version}, expected {v}); "
+                               "run backward before the optimizer step / in-place update")
+    return ctx.params
+
+
 def _lin_bwd(dz, a, W, pro_a, need_da=True, x3=False):
     """Linear backward pieces for z = pro(a)·W^T + b given dz:
     dW = dz^T·pro(a) (TN, prologue re-applied to the stored pre-activation),
@@ -115,6 +132,9 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_hidden, precision, *params):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("wf3d: the gradient with respect to the input cloud is not computed (the first per-point "
+                                      "layer's backward never forms dz); detach the cloud or use the reference encoder")
         B, N, Din = x.shape
         M = B * N
         x2 = x.reshape(M, Din)
@@ -160,7 +180,7 @@ class EncoderFn(torch.autograd.Function):
         C = pf.shape[1]
         po = ops.pool4_fwd(pf.view(B, N, C), valid, packed=True)          # [max | avg] (PointNetEncoder.py:115), [mean | max]
         ctx.n_hidden, ctx.dims, ctx.split = n_hidden, (B, N, C), split
-        ctx.params = params
+        _keep_params(ctx, params)
         ctx.saved = (x2, valid, zs, stats, hs, po.arg_m, po.arg_u, po.cnt)
         ctx.nvalid = po.nvalid
         ctx.wT = {i: ws[1] for i, ws in wsplit.items()}
@@ -173,7 +193,7 @@ class EncoderFn(torch.autograd.Function):
     def backward(ctx, dpooled, dpf, dupooled):
         nh, (B, N, C), split = ctx.n_hidden, ctx.dims, ctx.split
         M = B * N
-        params = ctx.params
+        params = _params(ctx)
         x2, valid, zs, stats, hs, arg_m, arg_u, cnt = _saved(ctx)
         grads = [None] * len(params)
         # the pooled cotangents are read as strided halves of the [B, 2C] gradients: no copies
@@ -258,7 +278,7 @@ class FusionFn(torch.autograd.Function):
     def forward(ctx, pooled, *F):
         pooled = pooled if pooled.stride(1) == 1 else pooled.contiguous()
         M = pooled.shape[0]
-        ctx.params = F
+        _keep_params(ctx, F)
         ctx.skinny = sk.ok(M, F[0], F[4], F[8]) and F[0].shape[0] % 16 == 0 and F[4].shape[0] % 16 == 0 \
             and pooled.stride(0) % 4 == 0
         if ctx.skinny:
@@ -276,7 +296,7 @@ class FusionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dgl):
-        F = ctx.params
+        F = _params(ctx)
         pooled, f0, s0, f3, s3 = _saved(ctx)
         G = [None] * 10
         dgl = dgl.contiguous()
@@ -350,7 +370,8 @@ class VertexFn(torch.autograd.Function):
             d = ops.ln_act_apply(z4, s4[0], s4[1], g4, be4, ACT_RELU, addend=r2)
             o = ops.gemm(d, Wf, NT, bias=bf)
         exist, counts = ops.vertex_finalize_fwd(o, V, vd)
-        ctx.params, ctx.dims = params, (B, V, vd)
+        _keep_params(ctx, params)
+        ctx.dims = (B, V, vd)
         # skinny path: c / d hold r1 / r2 (the sums are rebuilt on load)
         ctx.saved = (upooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d)
         ctx.save_for_backward(exist)
@@ -361,7 +382,7 @@ class VertexFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do3, dexist, _dcounts):
-        params = ctx.params
+        params = _params(ctx)
         B, V, vd = ctx.dims
         (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, W4, b4, g4, be4, Wf, bf, Wr1, br1, Wr2, br2) = params[:22]
         pooled, e, z1, s1, z2, s2, z3, s3, c, z4, s4, d = _saved(ctx)
@@ -482,7 +503,8 @@ class EdgeFn(torch.autograd.Function):
         else:
             logit = ops.gemm(z3, M10w, NT, bias=M10b, pro=Pro(ACT_GELU))
         probs = ops.edge_prob_fwd(logit, meta)
-        ctx.params, ctx.cfg = params, (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
+        _keep_params(ctx, params)
+        ctx.cfg = (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
         ctx.split, ctx.x3 = split, x3
         ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2)
         ctx.save_for_backward(probs)
@@ -490,7 +512,7 @@ class EdgeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dprobs):
-        params = ctx.params
+        params = _params(ctx)
         (P0w, P0b, P1g, P1b, P3w, P3b, P4g, P4b, Aw, Ab, Ow, Ob,
          M0w, M0b, M1g, M1b, M4w, M4b, M5g, M5b, M8w, M8b, M10w, M10b) = params
         B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta = ctx.cfg

@@ -89,5 +89,13 @@ class ClipAdam(torch.optim.Optimizer):
         check(lib.wf3d_clip_adam_step(vp(*P), vp(*G), vp(*M), vp(*V), numel, n, float(self.max_norm or 0.0), float(group["lr"]),
                                       float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                                       ws.data_ptr(), nws, norm.data_ptr(), _stream()), "clip_adam_step")
+        # the kernel wrote parameters, gradients and moments through raw pointers: tell autograd's version counters
+        # (a graph that still holds the old values must fail loudly, as it does after torch.optim.Adam.step())
+        bump = torch.autograd.graph.increment_version
+        for p in own:
+            bump(p)
+            bump(p.grad)
+        for g in keep:
+            bump(g)
         self.last_grad_norm = norm
         return loss
