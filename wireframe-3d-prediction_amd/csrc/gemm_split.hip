@@ -861,14 +861,18 @@ int cu_count() {
     return n;
 }
 
-// 6 = 256x256 tile on v_mfma_f32_16x16x32_bf16 (gemm_split_x16_kernel / its persistent form): problems with >= 512 tiles;
+// 6 = 256x256 tile on v_mfma_f32_16x16x32_bf16 (gemm_split_x16_kernel / its persistent form): >= 192 tiles (3/4 of the CUs) and N a
+//     multiple of 256 (a 128-wide output wastes half of every tile: 380 vs 420 us at 1,044,480 x 128 x 256);
 // 3 = 256x128 tile, three LDS stages, 32x32x16 MFMA (gemm_split_dma3_kernel): the smaller ones.
+// K is split only below 192 tiles: at 252 tiles (the edge MLP at cfg2) two K ranges + slabs + a combine launch cost more than
+// the idle quarter-wave they fill (scripts/bench_edge_gemms.py: 62 -> 48, 52 -> 26, 36 -> 25, 86 -> 61 us for its four GEMMs).
 // WF3D_SPLIT_DMA=3|6 forces one of them (tests/test_variants_gpu.py); the other round-1 variants live in
 // scripts/ablation/gemm_split_variants.hip.txt.
 int split_variant(int M, int N) {
     static const int forced = [] { const char* e = getenv("WF3D_SPLIT_DMA"); return e ? atoi(e) : 0; }();
     if (forced == 3 || forced == 6) return forced;
-    return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= 512 ? 6 : 3;
+    static const int min_tiles = [] { const char* e = getenv("WF3D_X16_MIN_TILES"); return e ? atoi(e) : 192; }();
+    return (long)wf3d_cdiv(M, 256) * wf3d_cdiv(N, 256) >= min_tiles && N % 256 == 0 ? 6 : 3;
 }
 
 void plan(int M, int N, int K, int& ksplit, int& kt_per) {
@@ -877,7 +881,8 @@ void plan(int M, int N, int K, int& ksplit, int& kt_per) {
     const long tiles = (long)wf3d_cdiv(M, bm) * wf3d_cdiv(N, bn);
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
-    if (tiles >= 256 || ktotal < 8) return;
+    static const int nosplit = [] { const char* e = getenv("WF3D_SPLIT_NOSPLIT_TILES"); return e ? atoi(e) : 192; }();
+    if (tiles >= nosplit || ktotal < 8) return;
     int want = (int)((512 + tiles - 1) / tiles);
     int ks = want < ktotal / 4 ? want : ktotal / 4;
     if (ks > 64) ks = 64;
