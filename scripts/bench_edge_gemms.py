@@ -34,5 +34,19 @@ def main():
             print(f"M={M:8d} N={N:4d} K={K:4d}  {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF")
 
 
+def wgrads():
+    """the edge MLP's two weight gradients, dW[256, 512] and dW^T[256, 128], over the edge rows (TN on sx8 operands)"""
+    dev = torch.device("cuda:0")
+    for K in (64512, 1044480):
+        for (Mo, No) in ((256, 512), (256, 128)):
+            a = ops.split_rows(torch.randn(K, Mo, device=dev))
+            b = ops.split_rows(torch.randn(K, No, device=dev))
+            t = timed(lambda: ops.gemm_split_tn(a, b))
+            print(f"K={K:8d} dW[{Mo}, {No}]  {t:8.1f} us  {2.0 * K * Mo * No / t / 1e6:6.1f} TF  {(Mo + No) * K * 4 / t / 1e6:5.2f} TB/s")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
+        wgrads()
+    else:
+        main()

@@ -968,7 +968,8 @@ void plan_tn(int Mo, int No, int K, int& ksplit, int& kt_per) {
     // at 2.0 TB/s, the 256 x 512 one on half the chip).
     const bool few = tiles <= 4;
     int ks = want < ktotal / (few ? 8 : 4) ? want : ktotal / (few ? 8 : 4);
-    const int cap = few ? 256 : 64;
+    static const int few_cap = [] { const char* e = getenv("WF3D_TN_FEW_CAP"); return e ? atoi(e) : 256; }();
+    const int cap = few ? few_cap : 64;
     if (ks > cap) ks = cap;
     if (few && ks >= 8) ks &= ~7;                 // multiples of 8: the XCD-mapped launch order applies
     if (ks < 2) return;
