@@ -280,6 +280,43 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     }
 }
 
+// The same sum for column counts / strides that are multiples of 4: 64 columns per workgroup as float4, the partial
+// rows split 16 ways, 4 loads (64 B) in flight per thread — twice the bytes in flight of the scalar form and 256-B
+// segments per row instead of 128-B ones (the [1024][3 x 2048] partials of an encoder layer: 25 MB).
+__global__ __launch_bounds__(256) void colsum_finalize4_kernel(const float* __restrict__ part, int nblk, size_t stride,
+                                                                int D, float* __restrict__ out) {
+    __shared__ f32x4 red[16][16];
+    const int c4 = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + c4 * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < D) {
+        const float* p = part + c;
+        int b = sub;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += *reinterpret_cast<const f32x4*>(p + (size_t)b * stride);
+            s1 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 16) * stride);
+            s2 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 32) * stride);
+            s3 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 48) * stride);
+        }
+        for (; b < nblk; b += 16) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)b * stride);
+    }
+    red[sub][c4] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sub == 0 && c < D) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][c4];
+        *reinterpret_cast<f32x4*>(out + c) = t;
+    }
+}
+
+void launch_finalize(const float* part, int nblk, size_t stride, int D, float* out, hipStream_t st, int tD = 0, int tK = 0) {
+    if (tK == 0 && D % 4 == 0 && stride % 4 == 0 && ((uintptr_t)part % 16 == 0) && ((uintptr_t)out % 16 == 0) && nblk >= 64)
+        hipLaunchKernelGGL(colsum_finalize4_kernel, dim3(wf3d_cdiv(D, 64)), dim3(256), 0, st, part, nblk, stride, D, out);
+    else
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part, nblk, stride, D, out, tD, tK);
+}
+
 // partial column sums: block (bx, by) sums rows [by*rpb, ...) of columns bx*256..
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int R, int D, int ld,
                                                               const float* __restrict__ w, int act, int rpb,
@@ -467,15 +504,13 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
     float* outs[3] = {dgamma, dbeta, dbias};
     if (dgamma && dbeta == dgamma + D && dbias == dbeta + D) {
         // the three outputs are one contiguous [3][D] buffer: a single finalize pass
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 32)), dim3(256), 0, st, part, nblk,
-                           (size_t)3 * D, 3 * D, dgamma);
+        launch_finalize(part, nblk, (size_t)3 * D, 3 * D, dgamma, st);
         WF3D_LAUNCH_CHECK();
         return WF3D_OK;
     }
     for (int k = 0; k < 3; ++k) {
         if (!outs[k]) continue;
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part + (size_t)k * D, nblk,
-                           (size_t)3 * D, D, outs[k]);
+        launch_finalize(part + (size_t)k * D, nblk, (size_t)3 * D, D, outs[k], st);
         WF3D_LAUNCH_CHECK();
     }
     return WF3D_OK;
@@ -510,9 +545,9 @@ extern "C" int wf3d_ln_act_bwd_first(const float* dh, const float* z, const floa
     if (wpr == 4) WF3D_BWD1(4); else if (wpr == 2) WF3D_BWD1(2); else WF3D_BWD1(1);
 #undef WF3D_BWD1
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(3 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)11 * D, 3 * D, dgamma);
+    launch_finalize(part, nblk, (size_t)11 * D, 3 * D, dgamma, st);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D * K, 32)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)11 * D, D * K, dW, D, K);
+    launch_finalize(part + 3 * D, nblk, (size_t)11 * D, D * K, dW, st, D, K);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
@@ -553,9 +588,9 @@ extern "C" int wf3d_ln_act_bwd_wsum(const float* dh, const float* z, const float
     else WF3D_BWDW(1, 1);
 #undef WF3D_BWDW
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(2 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)4 * D, 2 * D, dgamma);
+    launch_finalize(part, nblk, (size_t)4 * D, 2 * D, dgamma, st);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part + 3 * D, nblk, (size_t)4 * D, D, wsum);
+    launch_finalize(part + 3 * D, nblk, (size_t)4 * D, D, wsum, st);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
@@ -600,7 +635,7 @@ extern "C" int wf3d_rowdot_act_bwd(const float* z, const float* dlogit, int R, i
                    case 16: WF3D_RB(16); break; case 32: WF3D_RB(32); break; default: WF3D_RB(64); break; }
 #undef WF3D_RB
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(2 * D, 32)), dim3(256), 0, st, part, nblk, (size_t)2 * D, 2 * D, dw);
+    launch_finalize(part, nblk, (size_t)2 * D, 2 * D, dw, st);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
@@ -622,8 +657,7 @@ extern "C" int wf3d_colsum(const float* x, int R, int D, int ld, const float* w,
     float* part = (float*)ws;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(wf3d_cdiv(D, 256), nrb), dim3(256), 0, st, x, R, D, ld, w, act, rpb, part);
     WF3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(wf3d_cdiv(D, 32)), dim3(256), 0, st, part, wf3d_cdiv(R, rpb),
-                       (size_t)D, D, out);
+    launch_finalize(part, wf3d_cdiv(R, rpb), (size_t)D, D, out, st);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
