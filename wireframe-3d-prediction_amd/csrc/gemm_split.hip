@@ -856,6 +856,12 @@ int cu_count() {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        // WF3D_RESERVED_CUS=r: the persistent kernel leaves r CUs (rounded to whole XCD-octets) to whatever else runs on the
+        // chip.  Its workgroups need a whole CU's LDS, so ONE CU held by another stream's kernel (a collective) leaves one of
+        // 256 workgroups waiting for a full round: +45-60 % on the launch (scripts/bench_contention.py).
+        const char* e = getenv("WF3D_RESERVED_CUS");
+        const int r = e ? atoi(e) : 0;
+        if (r > 0 && v - r >= 8) v = (v - r) / 8 * 8;
         return v;
     }();
     return n;
