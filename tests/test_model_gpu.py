@@ -442,9 +442,31 @@ def test_inplace_parameter_update_between_forward_and_backward_is_reported():
         out2["vertices"].sum().backward()
 
 
-def test_input_cloud_gradient_is_refused_not_silently_none():
+def test_input_cloud_gradient_matches_oracle(precision):
+    """A cloud with requires_grad (the reference supports it, train.py never asks): dx against the fp64 oracle run under
+    the kernels' own ReLU / arg-max decisions, element-wise."""
     from models.PointCloudToWireframe import PointCloudToWireframe
-    model = PointCloudToWireframe(8, 4).to(dev()).set_dropout(0.0)
-    x = torch.randn(1, 16, 8, device=dev(), requires_grad=True)
-    with pytest.raises(NotImplementedError, match="input cloud"):
-        model(x, torch.tensor([4], device=dev()))
+    torch.manual_seed(12)
+    V = 5
+    model = PointCloudToWireframe(8, V).to(dev()).set_dropout(0.0)
+    model.train()
+    for seed in range(40, 72):
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(2, 48, 8, generator=gen)
+        xd = x.to(dev()).requires_grad_()
+        counts = torch.tensor([5, 3])
+        out = model(xd, counts.to(dev()))
+        frozen, n_border = H.capture_decisions(out, model)
+        if n_border == 0:
+            break
+    else:
+        pytest.fail("no borderline-free input found")
+    cot = {k: torch.randn(out[k].shape, generator=gen) for k in ("vertices", "existence_probabilities", "edge_probs")}
+    sum((out[k] * cot[k].to(dev())).sum() for k in cot).backward()
+    assert xd.grad is not None and xd.grad.shape == x.shape
+    P = oracle.params_from_module(model, dtype=torch.float64)
+    x64 = x.double().requires_grad_()
+    ref = oracle.model_forward(P, x64, counts, V, training=True, frozen=frozen)
+    sum((ref[k] * cot[k].double()).sum() for k in cot).backward()
+    e = H.elem_err(xd.grad.cpu().numpy(), x64.grad.numpy())
+    assert e < (1e-4 if precision == "fp32" else 5e-4), e

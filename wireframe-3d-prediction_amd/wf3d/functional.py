@@ -132,9 +132,9 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_hidden, precision, *params):
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("wf3d: the gradient with respect to the input cloud is not computed (the first per-point "
-                                      "layer's backward never forms dz); detach the cloud or use the reference encoder")
+        # a cloud that requires grad (train.py never asks) sends the first layer's backward down the general path, which
+        # forms dz and from it dx = dz . W
+        ctx.want_dx = ctx.needs_input_grad[0]
         B, N, Din = x.shape
         M = B * N
         x2 = x.reshape(M, Din)
@@ -196,6 +196,7 @@ class EncoderFn(torch.autograd.Function):
         params = _params(ctx)
         x2, valid, zs, stats, hs, arg_m, arg_u, cnt = _saved(ctx)
         grads = [None] * len(params)
+        dx = None
         # the pooled cotangents are read as strided halves of the [B, 2C] gradients: no copies
         dmmax = dmavg = dumean = dumax = None
         if dpooled is not None:
@@ -221,7 +222,7 @@ class EncoderFn(torch.autograd.Function):
         # pre-LN output of Linear i (fp32) and, in split mode, dz_s = the same in sx8.
         for i in range(nh, -1, -1):
             W = params[4 * i]
-            if i == 0 and nh > 0 and _split_ok(M, W.shape[0], split) and ops.first_layer_ok(x2, W):
+            if i == 0 and nh > 0 and not ctx.want_dx and _split_ok(M, W.shape[0], split) and ops.first_layer_ok(x2, W):
                 # layer 0: LN/ReLU backward, bias and WEIGHT gradient in one pass over (dh, z); dz is never written
                 g, be = params[2], params[3]
                 grads[2], grads[3], grads[1], grads[0] = ops.ln_act_bwd_first(dh, zs[0], x2, stats[0][0], stats[0][1], g, be, ACT_RELU)
@@ -261,10 +262,12 @@ class EncoderFn(torch.autograd.Function):
                     dh = ops.gemm_split(dz_s, ctx.wT[i] if i in ctx.wT else ops.split_rows(W, transpose=True))     # dgrad: dz · W
                 else:
                     dh = ops.gemm(dz, W, NN)
+            elif ctx.want_dx:
+                dx = ops.gemm(dz, W, NN).view(B, N, -1)           # at layer 0 dz is always the fp32 tensor
             del dz, dz_s
             dz = dz_s = None
         ctx.saved = None
-        return (None, None, None, *grads)
+        return (dx, None, None, *grads)
 
 
 class FusionFn(torch.autograd.Function):
