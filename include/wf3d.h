@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WF3D_VERSION 100
+#define WF3D_VERSION 101 /* 101: wf3d_gemm_t gained `x3` (appended) */
 
 #define WF3D_OK 0
 #define WF3D_ERR_ARG (-1)

@@ -197,7 +197,7 @@ def load():
             raise RuntimeError(f"wf3d: libwf3d.so lacks symbol {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.wf3d_version() < 100:
+    if lib.wf3d_version() < 101:
         raise RuntimeError("wf3d: libwf3d.so is stale; rebuild it")
     _lib = lib
     return lib
