@@ -427,14 +427,25 @@ __global__ __launch_bounds__(1024) void skinny_reduce_kernel(const wf3d_skinny_r
     const int col = blockIdx.x * 64 + lane, K = q.K;
     const bool cv = col < K;
     const bool ln = q.z != nullptr;
-    for (int m = 0; m < M; ++m) {
-        float v = 0.f;
+    // eight rows at a time (sixteen ran 2.5x slower): the eight loads of a slab are independent and go out back to back (one row at a time is a
+    // chain of M x slabs/16 dependent round trips)
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (cv) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                for (int s = wave; s < q.nslab[i]; s += 16) v += q.slabs[i][((size_t)s * M + m) * K + col];
+                for (int s = wave; s < q.nslab[i]; s += 16) {
+                    const float* base = q.slabs[i] + ((size_t)s * M + m0) * K + col;
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = m0 + j < M ? base[(size_t)j * K] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += t[j];
+                }
         }
-        s_v[wave][m][lane] = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (m0 + j < M) s_v[wave][m0 + j][lane] = v[j];
     }
     __syncthreads();
     const float gam = (ln && cv) ? q.gamma[col] : 0.f, bet = (ln && cv) ? q.beta[col] : 0.f;
