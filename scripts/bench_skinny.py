@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-launch time of the skinny (M = batch rows) kernels at the fusion-MLP / vertex-head shapes of cfg2 (csrc/skinny.hip),
-beside the bytes each launch has to move.  `python scripts/bench_skinny.py [M]`"""
+beside the bytes each launch has to move.  `python scripts/bench_skinny.py [M]`
+The loop is HOST-bound below ~15 us per call (ctypes + struct filling): for GPU-side durations run it under
+`rocprofv3 --kernel-trace --stats` with ONLY=<layer name> and read the per-kernel averages."""
 import os
 import sys
 
@@ -34,8 +36,9 @@ def rnd(*s):
 
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 print(f"M = {M}")
-for name, N, K in [("fusion.0", 2048, 1024), ("fusion.3", 1024, 2048), ("fusion.6", 512, 1024), ("vertex_mlp1", 4096, 512),
-                   ("vertex_mlp2", 2048, 4096), ("vertex_mlp3", 2048, 2048), ("vertex_mlp4", 1024, 2048), ("final", 256, 1024)]:
+ONLY = os.environ.get("ONLY")
+for name, N, K in [s_ for s_ in [("fusion.0", 2048, 1024), ("fusion.3", 1024, 2048), ("fusion.6", 512, 1024), ("vertex_mlp1", 4096, 512),
+                   ("vertex_mlp2", 2048, 4096), ("vertex_mlp3", 2048, 2048), ("vertex_mlp4", 1024, 2048), ("final", 256, 1024)] if not ONLY or s_[0] == ONLY]:
     X, W, b = rnd(M, K), rnd(N, K) * K ** -0.5, rnd(N)
     g, be = rnd(K), rnd(K)
     (Xp, part, _), = sk.fwd(M, sk.Fwd(rnd(M, 64), rnd(K, 64), None, stats=True)) if K % 16 == 0 else (None, None, None)
