@@ -31,15 +31,15 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _case(seed, B, N, V, counts):
+def _case(seed, B, N, V, counts, din=8):
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, N, 8, generator=g)
+    x = torch.randn(B, N, din, generator=g)
     x[0, N - N // 4:] = 0.0                       # zero-padded tail in cloud 0 (mask-aware vs unmasked pools differ)
     cot = None
     return x, torch.tensor(counts), g, cot
 
 
-def _run(precision, B, N, V, counts):
+def _run(precision, B, N, V, counts, din=8):
     from wf3d import config
     from models.PointCloudToWireframe import PointCloudToWireframe
     old = (config.precision(), config.SPLIT_MIN_ROWS)
@@ -47,7 +47,7 @@ def _run(precision, B, N, V, counts):
     config.SPLIT_MIN_ROWS = 1
     try:
         torch.manual_seed(20)
-        model = PointCloudToWireframe(8, V).to(dev()).set_dropout(0.0)
+        model = PointCloudToWireframe(din, V).to(dev()).set_dropout(0.0)
         model.train()
         # give LayerNorm affines and biases non-trivial values (default init is gamma=1, beta=0)
         with torch.no_grad():
@@ -55,7 +55,7 @@ def _run(precision, B, N, V, counts):
                 if p.dim() == 1:
                     p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
         for seed in range(100, 132):
-            x, cnt, gen, _ = _case(seed, B, N, V, counts)
+            x, cnt, gen, _ = _case(seed, B, N, V, counts, din)
             model.zero_grad(set_to_none=True)
             out = model(x.to(dev()), cnt.to(dev()))
             frozen, n_border = H.capture_decisions(out, model)
@@ -127,6 +127,19 @@ SWEEP = [
 @pytest.mark.parametrize("B,N,V,counts", SWEEP)
 def test_frozen_gradients_shape_sweep(precision, B, N, V, counts):
     fwd, errs, seed = _run(precision, B, N, V, counts)
+    for k, (a, b) in fwd.items():
+        assert a < TOL and b < TOL, (k, a, b)
+    tol = TOL if precision == "fp32" else 5e-4
+    bad = [(n, e) for n, e in errs.items() if not e <= tol]
+    assert not bad, (seed, bad)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("din", [3, 6, 11, 16])
+def test_frozen_gradients_other_input_widths(precision, din):
+    """input_dim other than the dataset's 8 (xyz only, no colour, wider than the fused first-layer kernel's 8 columns):
+    the first Linear then runs on the general GEMM path, forward and backward."""
+    fwd, errs, seed = _run(precision, 2, 40, 6, [6, 4], din=din)
     for k, (a, b) in fwd.items():
         assert a < TOL and b < TOL, (k, a, b)
     tol = TOL if precision == "fp32" else 5e-4
