@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WF3D_VERSION 101 /* 101: wf3d_gemm_t gained `x3` (appended) */
+#define WF3D_VERSION 102 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended) */
 
 #define WF3D_OK 0
 #define WF3D_ERR_ARG (-1)
@@ -87,6 +87,10 @@ typedef struct wf3d_gemm_t {
                             split into bf16 (hi, lo) while they are staged into LDS and multiplied as
                             hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; relative error
                             ~2^-16 per product).  Ignored for M <= 64 (32-row tile).                       */
+    const float* lr_u;   /* epilogue low-rank term  C += U[M, lr_k] . V[N, lr_k]^T  (exact fp32), lr_k = 0..4, 0 = none:  */
+    const float* lr_v;   /* the coordinate columns of the first edge Linear — Pa = F.Wa^T + c.Wc^T, EdgePredictor.py:     */
+    int lr_k;            /* 130-137 — ride on the GEMM that already writes Pa instead of a K = 3 GEMM with accumulate      */
+    int ld_lr_u, ld_lr_v;
 } wf3d_gemm_t;
 
 size_t wf3d_gemm_ws_bytes(int M, int N, int K, int layout);
@@ -342,10 +346,12 @@ int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const float* cv, con
                           float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
                           float drop_p, uint32_t drop_seed, void* h_sx8, void* stream);
 /* dPa[v] / dPb[v] = segmented sums of dpre over the edges where v is i / j, and
- * dcv[v] = sum over incident edges of (dpre[e]·wdelta)(c_v - c_other)/delta[e]. */
+ * dcv[v] = sum over incident edges of (dpre[e]·wdelta)(c_v - c_other)/delta[e]
+ *          (+ dPa[v]·Wc + dPb[v]·Wd when wcoord != NULL: wcoord[c * wcoord_stride + 0..5] = [Wc[c, :] | Wd[c, :]], the
+ *          coordinate columns 2H..2H+5 of edge_mlp[0].weight, EdgePredictor.py:130-137). */
 int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,
                        int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample, int Rv,
-                       int H, float* dPa, float* dPb, float* dcv, void* stream);
+                       int H, float* dPa, float* dPb, float* dcv, const float* wcoord, int wcoord_stride, void* stream);
 
 /* probs[s, j] = sigmoid(logit[eoff[s] + j]) for j < E_s and exactly 0.0 for the padding j >= E_s: the whole padded
  * [B, max_e] output of PointCloudToWireframe.py:103-112 in one pass (no zero-fill first), and its backward. */

@@ -581,3 +581,22 @@ def test_gemm_x3_ln_prologue_addend_accumulate(ops, act, M, N, K):
     dz = rnd(M, N, seed=26)
     gw = ops.gemm(dz, z, ops.TN, pro=pro, x3=True)
     assert rel(gw, dz.double().cpu().T @ h) < TOL_SPLIT
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K,k,x3", [(2048, 512, 512, 3, True), (300, 200, 100, 3, False), (33, 130, 64, 4, False),
+                                        (128, 128, 8192, 1, False), (2048, 1536, 512, 2, True)])
+def test_gemm_lowrank_epilogue(ops, layout, M, N, K, k, x3):
+    """C = A.B^T + bias + U.V^T with the rank-k (k <= 4) term added in the epilogue (exact fp32), incl. the split-K
+    combine paths and strided U / V views (column slices of wider matrices, as the edge head passes them)."""
+    A, B, bias = rnd(M, K, seed=31), rnd(N, K, seed=32), rnd(N, seed=33)
+    Uw, Vw = rnd(M, 7, seed=34), rnd(N, 9, seed=35)
+    U, V = Uw[:, 2:2 + k], Vw[:, 5:5 + k]
+    want = ref64(lambda a, b, c, u, v: a @ b.T + c + u @ v.T, A, B, bias, U.contiguous(), V.contiguous())
+    if layout == ops.NT:
+        got = ops.gemm(A, B, ops.NT, bias=bias, lowrank=(U, V), x3=x3)
+    elif layout == ops.NN:
+        got = ops.gemm(A, B.T.contiguous(), ops.NN, bias=bias, lowrank=(U, V), x3=x3)
+    else:
+        got = ops.gemm(A.T.contiguous(), B.T.contiguous(), ops.TN, bias=bias, lowrank=(U, V), x3=x3)
+    assert rel(got, want) < (TOL_SPLIT if x3 else TOL_GEMM)

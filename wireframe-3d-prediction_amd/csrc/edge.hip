@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
                                                         const int32_t* __restrict__ eoff,
                                                         const int32_t* __restrict__ vsample, int H,
                                                         float* __restrict__ dPa, float* __restrict__ dPb,
-                                                        float* __restrict__ dcv) {
-    extern __shared__ __attribute__((aligned(16))) float red[];     // [2][H] + [4][3]
+                                                        float* __restrict__ dcv, const float* __restrict__ wcoord,
+                                                        int wcoord_stride) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [2][H] + [4][3] + [4][3]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x;
     const int s = vsample[r];
@@ -230,12 +231,29 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
         }
         __syncthreads();
     }
+    // the coordinate columns of the first edge Linear: pre also held c_i . Wc^T + c_j . Wd^T, so this vertex's coordinates
+    // receive dPa[r] . Wc + dPb[r] . Wd — two [rows, H] x [H, 3] products that would otherwise be separate launches
+    float qx = 0.f, qy = 0.f, qz = 0.f;
     for (int c = threadIdx.x; c < H; c += 256) {
-        dPa[(size_t)r * H + c] = ra[c];
-        dPb[(size_t)r * H + c] = rb[c];
+        const float a = ra[c], b = rb[c];
+        dPa[(size_t)r * H + c] = a;
+        dPb[(size_t)r * H + c] = b;
+        if (wcoord) {
+            const float* w = wcoord + (size_t)c * wcoord_stride;
+            qx += a * w[0] + b * w[3]; qy += a * w[1] + b * w[4]; qz += a * w[2] + b * w[5];
+        }
     }
-    if (threadIdx.x < 3)
-        dcv[r * 3 + threadIdx.x] = (rc[threadIdx.x] + rc[3 + threadIdx.x]) + (rc[6 + threadIdx.x] + rc[9 + threadIdx.x]);
+    float* rq = red + 2 * H + 12;
+    if (wcoord) {
+        qx = wf3d_wave_sum(qx); qy = wf3d_wave_sum(qy); qz = wf3d_wave_sum(qz);
+        if (lane == 0) { rq[wave * 3] = qx; rq[wave * 3 + 1] = qy; rq[wave * 3 + 2] = qz; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        float v = (rc[threadIdx.x] + rc[3 + threadIdx.x]) + (rc[6 + threadIdx.x] + rc[9 + threadIdx.x]);
+        if (wcoord) v += (rq[threadIdx.x] + rq[3 + threadIdx.x]) + (rq[6 + threadIdx.x] + rq[9 + threadIdx.x]);
+        dcv[r * 3 + threadIdx.x] = v;
+    }
 }
 
 // ---- sigmoid into the padded [B, max_E] output; the padding (exactly 0.0) is written here too ----
@@ -361,18 +379,20 @@ static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, cons
 
 extern "C" int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,
                                   int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample,
-                                  int Rv, int H, float* dPa, float* dPb, float* dcv, void* stream) {
+                                  int Rv, int H, float* dPa, float* dPb, float* dcv, const float* wcoord,
+                                  int wcoord_stride, void* stream) {
     WF3D_CHECK(Rv >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: bad dims");
+    WF3D_CHECK(!wcoord || wcoord_stride >= 6, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: wcoord rows hold [Wc | Wd] = 6 floats");
     WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_bwd: hidden %d must be a multiple of 4, <= 2048", H);
     if (Rv == 0) return WF3D_OK;
     WF3D_CHECK(dpre && delta && cv && wdelta && voff && eoff && vsample && dPa && dPb && dcv, WF3D_ERR_ARG,
                "wf3d_edge_pair_bwd: null pointer");
     const int ns = wf3d_cdiv(H, 256);
-    const size_t lds = ((size_t)2 * H + 16) * sizeof(float);
+    const size_t lds = ((size_t)2 * H + 32) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define WF3D_PB(NS_)                                                                                                 \
     hipLaunchKernelGGL((pair_bwd_kernel<NS_>), dim3(Rv), dim3(256), lds, st, dpre, delta, cv, wdelta, wdelta_stride,   \
-                       voff, eoff, vsample, H, dPa, dPb, dcv)
+                       voff, eoff, vsample, H, dPa, dPb, dcv, wcoord, wcoord_stride)
     if (ns <= 1) WF3D_PB(1); else if (ns <= 2) WF3D_PB(2); else if (ns <= 4) WF3D_PB(4); else WF3D_PB(8);
 #undef WF3D_PB
     WF3D_LAUNCH_CHECK();

@@ -50,6 +50,7 @@ struct GemmParams {
     float* slab;
     int vecA, vecB, vecP;
     int nbm, nbn;
+    const float* lr_u; const float* lr_v; int lr_k, ld_lr_u, ld_lr_v;    // epilogue: C += U[M, lr_k] . V[N, lr_k]^T
 };
 
 // ---- staging: global -> registers ------------------------------------------
@@ -452,6 +453,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
             const int col = n0 + (wn * TN + j) * 32 + l31;
             if (col >= p.N) continue;
             const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+            float lv[4] = {0.f, 0.f, 0.f, 0.f};             // this column's row of V (low-rank epilogue term, lr_k <= 4)
+            if (!split && p.lr_k > 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lv[k] = k < p.lr_k ? p.lr_v[(size_t)col * p.ld_lr_v + k] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -461,6 +467,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
                     p.slab[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
                 } else {
                     v += bv;
+                    if (p.lr_k > 0) {
+                        const float* u = p.lr_u + (size_t)row * p.ld_lr_u;
+                        float t = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t += k < p.lr_k ? u[k] * lv[k] : 0.f;
+                        v += t;
+                    }
                     if (p.addend) v += p.addend[(size_t)row * p.ld_addend + col];
                     float* c = p.C + (size_t)row * p.ldc + col;
                     if (p.accumulate) v += *c;
@@ -509,6 +522,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmParams p) {
         float v = 0.f;
         for (int z = 0; z < p.ksplit; ++z) v += p.slab[(size_t)z * total + idx];
         if (p.bias) v += p.bias[col];
+        for (int k = 0; k < p.lr_k; ++k) v += p.lr_u[(size_t)row * p.ld_lr_u + k] * p.lr_v[(size_t)col * p.ld_lr_v + k];
         if (p.addend) v += p.addend[(size_t)row * p.ld_addend + col];
         float* c = p.C + (size_t)row * p.ldc + col;
         if (p.accumulate) v += *c;
@@ -547,6 +561,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_wide(const GemmParams 
         for (int e = 0; e < 4; ++e) {
             float v = acc[e];
             if (p.bias) v += p.bias[col + e];
+            for (int k = 0; k < p.lr_k; ++k) v += p.lr_u[(size_t)row * p.ld_lr_u + k] * p.lr_v[(size_t)(col + e) * p.ld_lr_v + k];
             if (p.addend) v += p.addend[(size_t)row * p.ld_addend + col + e];
             if (p.accumulate) v += c[e];
             c[e] = v;
@@ -647,6 +662,10 @@ extern "C" int wf3d_gemm(const wf3d_gemm_t* d, void* stream) {
     p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.addend = d->addend;
     p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
     p.ld_addend = d->ld_addend;
+    WF3D_CHECK(d->lr_k >= 0 && d->lr_k <= 4, WF3D_ERR_ARG, "wf3d_gemm: lr_k must be 0..4");
+    WF3D_CHECK(d->lr_k == 0 || (d->lr_u && d->lr_v && d->ld_lr_u >= d->lr_k && d->ld_lr_v >= d->lr_k), WF3D_ERR_ARG,
+               "wf3d_gemm: low-rank term needs U, V and leading dimensions >= lr_k");
+    p.lr_u = d->lr_u; p.lr_v = d->lr_v; p.lr_k = d->lr_k; p.ld_lr_u = d->ld_lr_u; p.ld_lr_v = d->ld_lr_v;
     p.pmu = d->pro_mu; p.prs = d->pro_rs; p.pgam = d->pro_gamma; p.pbet = d->pro_beta;
     p.has_ln = d->pro_enable && d->pro_mu != nullptr;
     p.has_affine = d->pro_enable && d->pro_gamma != nullptr;

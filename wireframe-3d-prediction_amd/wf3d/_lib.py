@@ -30,6 +30,7 @@ class GemmDesc(ctypes.Structure):
         ("accumulate", c_int),
         ("ws", c_void_p), ("ws_bytes", c_size_t),
         ("x3", c_int),
+        ("lr_u", c_void_p), ("lr_v", c_void_p), ("lr_k", c_int), ("ld_lr_u", c_int), ("ld_lr_v", c_int),
     ]
 
 
@@ -141,7 +142,7 @@ SIGNATURES = {
     "wf3d_edge_pair_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf3d_edge_pair_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "wf3d_edge_prob_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_loss_cost_matrix": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                       c_int, c_void_p, c_void_p]),
@@ -197,7 +198,7 @@ def load():
             raise RuntimeError(f"wf3d: libwf3d.so lacks symbol {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.wf3d_version() < 101:
+    if lib.wf3d_version() < 102:
         raise RuntimeError("wf3d: libwf3d.so is stale; rebuild it")
     _lib = lib
     return lib

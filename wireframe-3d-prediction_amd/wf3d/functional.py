@@ -478,10 +478,9 @@ class EdgeFn(torch.autograd.Function):
         cx, lse = ops.attn_fwd(qkv, meta, H, heads, pa_, sd[1])
         Fm = ops.gemm(cx, Ow, NT, bias=Ob, addend=f, x3=x3)              # residual (EdgePredictor.py:114)
         Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + 3], M0w[:, 2 * H + 3:2 * H + 6]
-        Pa = ops.gemm(Fm, Wa, NT, bias=M0b, x3=x3)
-        ops.gemm(cv, Wc, NT, out=Pa, accumulate=True)
-        Pb = ops.gemm(Fm, Wb, NT, x3=x3)
-        ops.gemm(cv, Wd, NT, out=Pb, accumulate=True)
+        # the coordinate columns ride on the two GEMMs as a rank-3 epilogue term (exact fp32)
+        Pa = ops.gemm(Fm, Wa, NT, bias=M0b, x3=x3, lowrank=(cv, Wc))
+        Pb = ops.gemm(Fm, Wb, NT, x3=x3, lowrank=(cv, Wd))
         # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
         split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
         if split:
@@ -583,7 +582,7 @@ class EdgeFn(torch.autograd.Function):
         # split first layer backward
         dW0 = torch.empty_like(M0w)           # every column is written below: Wa | Wb | Wc | Wd | w_delta
         dW0[:, 2 * H + 6].copy_(wsum)
-        dPa, dPb, dcv = ops.edge_pair_bwd(dpre, delta, cv, M0w, meta)
+        dPa, dPb, dcv = ops.edge_pair_bwd(dpre, delta, cv, M0w, meta, coord=True)     # dcv includes dPa·Wc + dPb·Wd
 
         def first_layer_leaves():
             ops.gemm(dPa, Fm, TN, out=dW0[:, :H], x3=x3)
@@ -596,8 +595,6 @@ class EdgeFn(torch.autograd.Function):
         Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + 3], M0w[:, 2 * H + 3:2 * H + 6]
         dF = ops.gemm(dPa, Wa, NN, x3=x3)
         ops.gemm(dPb, Wb, NN, out=dF, accumulate=True, x3=x3)
-        ops.gemm(dPa, Wc, NN, out=dcv, accumulate=True)
-        ops.gemm(dPb, Wd, NN, out=dcv, accumulate=True)
         # F = f + out_proj(ctx)
         G[11], G[10] = lv.run(lambda: (ops.colsum(dF), ops.gemm(dF, cx, TN, x3=x3)), dF, cx)
         dcx = ops.gemm(dF, Ow, NN, x3=x3)

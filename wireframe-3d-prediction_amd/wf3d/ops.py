@@ -76,9 +76,10 @@ class Pro:
         self.drop_p, self.seed = float(drop_p), int(seed) & 0xFFFFFFFF
 
 
-def gemm(a, b, layout, bias=None, addend=None, out=None, accumulate=False, pro=None, x3=False):
+def gemm(a, b, layout, bias=None, addend=None, out=None, accumulate=False, pro=None, x3=False, lowrank=None):
     """C = pro(A)·B (+bias) (+addend) (+C).  NT: a[M,K] b[N,K]; NN: a[M,K] b[K,N]; TN: a[K,M] b[K,N].
-    x3=True: bf16x3 arithmetic on the fp32 operands (split while staged; see wf3d_gemm_t.x3); default exact fp32."""
+    x3=True: bf16x3 arithmetic on the fp32 operands (split while staged; see wf3d_gemm_t.x3); default exact fp32.
+    lowrank=(U[M,k], V[N,k]), k <= 4: C += U·V^T in the epilogue (exact fp32; unit inner stride, any row stride)."""
     _need_cuda(a, b, bias, addend, out)
     a, b = _rows2d(a), _rows2d(b)
     if layout == NT:
@@ -127,6 +128,14 @@ def gemm(a, b, layout, bias=None, addend=None, out=None, accumulate=False, pro=N
         d.drop_p, d.drop_seed = pro.drop_p, pro.seed
     d.accumulate = 1 if accumulate else 0
     d.x3 = 1 if x3 else 0
+    if lowrank is not None:
+        u, v = lowrank
+        _need_cuda(u, v)
+        if u.dim() != 2 or v.dim() != 2 or u.shape[0] != M or v.shape[0] != N or u.shape[1] != v.shape[1] or u.shape[1] > 4 \
+                or u.stride(1) != 1 or v.stride(1) != 1:
+            raise RuntimeError("wf3d.gemm: lowrank needs U[M,k], V[N,k] with k <= 4 and unit inner stride")
+        d.lr_u, d.lr_v, d.lr_k = _p(u), _p(v), u.shape[1]
+        d.ld_lr_u, d.ld_lr_v = u.stride(0) if M > 1 else u.shape[1], v.stride(0) if N > 1 else v.shape[1]
     lib = _lib.load()
     nb = lib.wf3d_gemm_ws_bytes(M, N, K, layout)
     ws = scratch(nb, a.device)
@@ -471,16 +480,21 @@ def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None):
     return pre, mu, rs, delta, h
 
 
-def edge_pair_bwd(dpre, delta, cv, W0, meta):
+def edge_pair_bwd(dpre, delta, cv, W0, meta, coord=False):
+    """coord=True: dcv also receives dPa·Wc + dPb·Wd (the coordinate columns 2H..2H+5 of W0)."""
     _need_cuda(dpre, delta, cv, W0)
     H = dpre.shape[1]
     wd, stride = _wdelta(W0, H)
+    wc = W0[:, 2 * H:2 * H + 6] if coord else None
+    if coord and (W0.dim() != 2 or W0.shape[1] < 2 * H + 6 or W0.stride(1) != 1):
+        raise RuntimeError("wf3d.edge_pair_bwd: W0 must be [H, >= 2H+6] with unit inner stride")
     dev = dpre.device
     dPa = torch.empty(meta.Rv, H, dtype=torch.float32, device=dev)
     dPb = torch.empty(meta.Rv, H, dtype=torch.float32, device=dev)
     dcv = torch.empty(meta.Rv, 3, dtype=torch.float32, device=dev)
     check(_lib.load().wf3d_edge_pair_bwd(_p(dpre), _p(delta), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
-                                         _p(meta.vsample), meta.Rv, H, _p(dPa), _p(dPb), _p(dcv), _stream()),
+                                         _p(meta.vsample), meta.Rv, H, _p(dPa), _p(dPb), _p(dcv), _p(wc),
+                                         W0.stride(0) if coord else 0, _stream()),
           "edge_pair_bwd")
     return dPa, dPb, dcv
 
