@@ -592,7 +592,7 @@ class EdgeFn(torch.autograd.Function):
             return ops.colsum(dPa)
         G[13] = lv.run(first_layer_leaves, dPa, dPb, Fm, cv, dW0)
         G[12] = dW0
-        Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + 3], M0w[:, 2 * H + 3:2 * H + 6]
+        Wa, Wb = M0w[:, :H], M0w[:, H:2 * H]
         dF = ops.gemm(dPa, Wa, NN, x3=x3)
         ops.gemm(dPb, Wb, NN, out=dF, accumulate=True, x3=x3)
         # F = f + out_proj(ctx)
