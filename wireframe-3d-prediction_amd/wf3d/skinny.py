@@ -6,6 +6,7 @@ per-16-column (mean, M2) partials of it; the launch that consumes act(LN(z)) mer
 alternates two launches per stage: `bwd` (weight/bias gradient + dgrad partial slabs, for up to 4 Linears that are
 ready together) and `reduce` (slab sum + the elementwise half of the next LayerNorm backward)."""
 import ctypes
+import os
 
 import torch
 
@@ -105,12 +106,15 @@ class Bwd:
 
 def _pick_nc(N, K):
     """dgrad chunk height (weight rows per workgroup).  A chunk of nc rows costs one slab of M*K*4 bytes (written, read
-    back by reduce) and nc/2 x 4 fp32 MFMAs of 64 cycles per wave: 128 rows for the big matrices (slab bytes bounded)
-    and for narrow outputs (K <= 1024: reduce runs on K/64 workgroups only, so few slabs), 64 for the others (half the
-    per-workgroup latency, twice the workgroups)."""
-    if N < 128:
-        return max(2, N + (N & 1)) if N < 64 else 64
-    return 128 if (N * K > (4 << 20) or K <= 1024) else 64
+    back by reduce) and nc/2 x 4 fp32 MFMAs of 64 cycles per wave.  Measured GPU-side over the nine head layers of cfg2
+    (rocprofv3, bwd + reduce per step): nc = 32: 305 us, 64: 270 us, 128: 289 us, the earlier mixed rule (128 for the big
+    and the narrow layers) 292 us — so 64 everywhere (WF3D_SKINNY_NC forces another value)."""
+    force = os.environ.get("WF3D_SKINNY_NC")
+    if force:
+        return min(int(force), max(2, N + (N & 1)))
+    if N < 64:
+        return max(2, N + (N & 1))
+    return 64
 
 
 def bwd(M, *specs):
