@@ -27,7 +27,9 @@ for K, N in layers:
     cases.append((f"NT     K={K} N={N}", lambda X=X, W=W, o=o_nt: ops.gemm(X, W, ops.NT, out=o), fl))
     cases.append((f"NN     K={N} N={K}", lambda G=G, W=W, o=o_nn: ops.gemm(G, W, ops.NN, out=o), fl))
     Xs, Ws, Gs, WTs = ops.split_rows(X), ops.split_rows(W), ops.split_rows(G), ops.split_rows(W, transpose=True)
+    bias = torch.randn(N, device=dev)
     cases.append((f"SPLIT NT K={K} N={N}", lambda Xs=Xs, Ws=Ws, o=o_nt: ops.gemm_split(Xs, Ws, out=o), fl))
+    cases.append((f"SPLIT NT+bias K={K} N={N}", lambda Xs=Xs, Ws=Ws, o=o_nt, b=bias: ops.gemm_split(Xs, Ws, bias=b, out=o), fl))
     cases.append((f"SPLIT dgrad K={N} N={K}", lambda Gs=Gs, WTs=WTs, o=o_nn: ops.gemm_split(Gs, WTs, out=o), fl))
     Gts, Xts = ops.split_transpose(Gs, in_sx8=True), ops.split_transpose(Xs, in_sx8=True)
     cases.append((f"SPLIT wgrad(NT on transposes) {N}x{K}", lambda a=Gts, b=Xts, o=o_tn: ops.gemm_split(a, b, out=o), fl))

@@ -29,6 +29,10 @@
 #define WF3D_NT_STORE 0    // persistent kernel: 1 = non-temporal C stores (experiment)
 #endif
 
+#ifndef WF3D_STAMP
+#define WF3D_STAMP 0       // diagnostic build: the persistent kernel records s_memtime at every slice start (scripts/stamp_gemm.py)
+#endif
+
 #ifndef WF3D_DMA_SCHED
 #define WF3D_DMA_SCHED 0   // 256x256 kernel: 0 = DMA pieces spread over the slice, 1 = over its first half, 2 = bunched at the top
 #endif
@@ -634,12 +638,109 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
 }
 
 // ---------------------------------------------------------------------------
-// Persistent form of the forward / dgrad kernel above (full tiles, no split-K): one workgroup per CU walks its
-// XCD's tiles slot, slot + S, ... and treats their k-slices as ONE stream — the last slices of a tile already DMA
-// the first A / B slices of the next, so a tile starts without the cold-miss prologue and without a workgroup
-// launch; its C stores drain behind the next tile's first slice (they are older than that slice's DMA pieces in
-// the in-order vmcnt queue, so the slice-end wait also retires them).
+// Persistent form of the forward / dgrad kernel above (full tiles, no split-K, no accumulate, 16-B aligned C): one
+// workgroup per CU walks its XCD's tiles slot, slot + S, ... and treats their k-slices as ONE stream — the last slices
+// of a tile already DMA the first A / B slices of the next, so a tile starts without the cold-miss prologue and without
+// a workgroup launch.
+//
+// Tile boundary (round 3).  The first version stored the finished tile in a burst between two slices, and with a bias
+// the compiler had put a bias load + `s_waitcnt vmcnt(0)` in front of every one of the 32 stores per lane (each store
+// waited for the one before it to be acknowledged).  Now:
+//   * the bias is the INITIAL value of the accumulators: the 16 values a lane needs for the next tile are fetched by
+//     four hidden (inline-asm) loads at the top of the current tile's last slice — older than that slice's DMA pieces,
+//     so the slice-end `vmcnt(4)` retires them — and enter the first MFMA of every accumulator as its C operand;
+//   * the stores of tile t are issued INSIDE the first slice of tile t + 1, row-tile by row-tile, each group of four
+//     right before the MFMAs that overwrite those accumulators.  That slice ends with `vmcnt(32)`: in the in-order
+//     queue everything up to this slice's last B piece has landed (B(s+1), A(s+1)), while 28 of the 32 stores and the
+//     A(s+2) pieces may still be in flight — the stores get a whole further slice before the next `vmcnt(4)` asks for
+//     them, instead of standing between the pipeline and its next slice.
 // ---------------------------------------------------------------------------
+#if WF3D_STAMP
+constexpr int STAMP_PER_WG = 1024;
+__device__ unsigned long long g_stamps[256 * STAMP_PER_WG];
+#endif
+
+__device__ __forceinline__ f32x4 gload16_asm(const float* src) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src) : "memory");    // completion: the caller's counted vmcnt
+    return v;
+}
+
+// LDS-DMA piece with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: half the address registers of
+// the flat form and no 64-bit add per piece.  `s_nop 3`: five wait states between a VALU-written SGPR (readfirstlane)
+// and the VMEM instruction that reads it as its base, should the compiler have formed the base that way.
+__device__ __forceinline__ void dma16_sbase(const float* sbase, unsigned voff_bytes, float* lds_wave_base) {
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff_bytes), "s"(sbase), "s"(lds) : "memory");
+}
+
+// One k32 slice of the 256x256 tile, software-pipelined ACROSS the barrier (round 3).  In-kernel stamps showed every
+// steady-state slice taking 3,900 cycles for 3,072 cycles of MFMA: after the slice-end barrier all eight waves issue
+// their first fragment reads at once and both waves of every SIMD wait for LDS.  Here the wait + barrier that publish
+// slice s+1 sit in front of the LAST row-tile of slice s: by then every LDS read of slice s has been issued (the
+// A fragments roll one row-tile ahead) and is drained by the same wait, so the stages of slice s are free and
+// slice s+1's are valid — and the first fragments of slice s+1 (its four B-hi fragments into a second register set,
+// A row-tile 0 into the rolling pair) are fetched while row-tile 7's twelve MFMAs run.  Row-tile 7 runs its B-lo group
+// first, which frees the B-lo registers for slice s+1's B-lo reads behind it.  One barrier per slice, as before.
+//   bhc / bhn: B-hi fragments of this / the next slice (two named sets, the caller alternates them).
+template <bool BIAS>
+__device__ __forceinline__ void x16p_slice(f32x4 (&acc)[8][4], f32x4 (&bhc)[4], f32x4 (&bhn)[4], f32x4 (&bl)[4], f32x4 (&pah)[2],
+                                           f32x4 (&pal)[2], const float* As, const float* Bs, const float* Asn, const float* Bsn,
+                                           int a_row, int b_row, int c_hi, int c_lo, const float* Ap, const float* Bp,
+                                           const unsigned (&aoff)[4], const unsigned (&boff)[4], float* dA, float* dB,
+                                           f32x4 (&init)[4]) {
+    // A fragments alternate between two register pairs by row-tile parity (8 row-tiles: the pair that row-tile 0 of
+    // the NEXT slice lands in is again pair 0 — no copies at the loop edge, so no wait for them either)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        pah[(i + 1) & 1] = *reinterpret_cast<const f32x4*>(As + a_row + (i + 1) * 16 * SBK + c_hi);
+        pal[(i + 1) & 1] = *reinterpret_cast<const f32x4*>(As + a_row + (i + 1) * 16 * SBK + c_lo);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 4) {      // B(s+1) first, A(s+2) last: the wait below skips exactly the 4 youngest pieces
+            if (i < 2) { dma16_sbase(Bp, boff[2 * i], dB + (2 * i) * 8 * SBK);     dma16_sbase(Bp, boff[2 * i + 1], dB + (2 * i + 1) * 8 * SBK); }
+            else       { dma16_sbase(Ap, aoff[2 * i - 4], dA + (2 * i - 4) * 8 * SBK); dma16_sbase(Ap, aoff[2 * i - 3], dA + (2 * i - 3) * 8 * SBK); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, pah[i & 1]), val = __builtin_bit_cast(bf16x8, pal[i & 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), val, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), vah, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // B(s+1) and A(s+1) landed (all but the 4 youngest pieces = A(s+2)); every read of this slice's stages is done.
+    // With a bias the wait names the init registers: their first reader (the tile epilogue) is ordered behind it.
+    if (BIAS) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(init[0]), "+v"(init[1]), "+v"(init[2]), "+v"(init[3]) :: "memory");
+    else      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // first fragments of slice s+1, in the order its MFMAs will ask for them
+    pal[0] = *reinterpret_cast<const f32x4*>(Asn + a_row + c_lo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bhn[j] = *reinterpret_cast<const f32x4*>(Bsn + b_row + j * 16 * SBK + c_hi);
+    pah[0] = *reinterpret_cast<const f32x4*>(Asn + a_row + c_hi);
+    __builtin_amdgcn_sched_barrier(0);
+    {   // row-tile 7 (pair 1): B-lo group first
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, pah[1]), val = __builtin_bit_cast(bf16x8, pal[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[7][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bsn + b_row + j * 16 * SBK + c_lo);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), val, acc[7][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), vah, acc[7][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool BIAS>
 __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitParams p) {
     __shared__ __attribute__((aligned(16))) float smem[5 * T4_A];          // 163,840 B: A x 3 stages, B x 2
     const int tid = threadIdx.x, lane = tid & 63;
@@ -654,25 +755,35 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
     const int xcnt = xcd < r8 ? q8 + 1 : q8;
     if (slot >= xcnt) return;
     const int ntile = (xcnt - slot + S - 1) / S;
-    const int ktotal = p.K / SBK;                                          // >= 2 (host-checked)
+    const int ktotal = p.K / SBK;                                          // even, >= 2 (host-checked)
 
-    // per-lane offsets of the 4 A and 4 B pieces inside a tile (full tiles only: no row clamping)
-    size_t aoff[4], boff[4];
+    // per-lane BYTE offsets of the 4 A and 4 B pieces inside a tile (full tiles only: no row clamping; 256 rows x
+    // pitch x 4 B < 2^32 is host-checked)
+    unsigned aoff[4], boff[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = (wave * 4 + q) * 8 + (lane >> 3);
         const int chunk = ((lane & 7) ^ swz16(row)) * 4;
-        aoff[q] = (size_t)row * p.lda + chunk;
-        boff[q] = (size_t)row * p.ldb + chunk;
+        aoff[q] = ((unsigned)row * (unsigned)p.lda + chunk) * 4u;
+        boff[q] = ((unsigned)row * (unsigned)p.ldb + chunk) * 4u;
     }
     auto tile_m0 = [&](int t) { return ((xbase + slot + t * S) / p.nbn) * 256; };
     auto tile_n0 = [&](int t) { return ((xbase + slot + t * S) % p.nbn) * 256; };
+    // lane (r16, g) of wave (wm, wn) holds C[m0 + wm*128 + i*16 + r16][n0 + wn*64 + j*16 + g*4 .. +3]
+    const unsigned crow16 = 16u * (unsigned)p.ldc;
+    const int lane_col = wn * 64 + g * 4;
+    const unsigned coff = (unsigned)(wm * 128 + r16) * (unsigned)p.ldc + lane_col;
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][4], init[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        init[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BIAS) init[j] = *reinterpret_cast<const f32x4*>(p.bias + tile_n0(0) + lane_col + j * 16);     // before any DMA: a plain, compiler-counted load
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = init[j];
     const int fs = swz16(r16);
     const int c_hi = ((2 * g) ^ fs) * 4, c_lo = ((2 * g + 1) ^ fs) * 4;
     const int a_row = (wm * 128 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
@@ -680,27 +791,64 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
 
     const float* Acur = p.A + (size_t)tile_m0(0) * p.lda;                  // scalar bases of the current / next tile
     const float* Bcur = p.B + (size_t)tile_n0(0) * p.ldb;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]) :: "memory");       // the bias loads are done before the counted DMA stream starts
     {   // prologue of the whole stream: A(0), B(0), A(1) of the first tile
         float* dA = smem + wave * 4 * 8 * SBK;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16_asm(Acur + aoff[q], dA + q * 8 * SBK);
+        for (int q = 0; q < 4; ++q) dma16_sbase(Acur, aoff[q], dA + q * 8 * SBK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16_asm(Bcur + boff[q], smemB + wave * 4 * 8 * SBK + q * 8 * SBK);
+        for (int q = 0; q < 4; ++q) dma16_sbase(Bcur, boff[q], smemB + wave * 4 * 8 * SBK + q * 8 * SBK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16_asm(Acur + aoff[q] + SBK, dA + T4_A + q * 8 * SBK);
+        for (int q = 0; q < 4; ++q) dma16_sbase(Acur + SBK, aoff[q], dA + T4_A + q * 8 * SBK);
     }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // fragments of the very first slice
+    f32x4 bhA[4], bhB[4], bl[4], pah[2], pal[2];
+    pal[0] = *reinterpret_cast<const f32x4*>(smem + a_row + c_lo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bhA[j] = *reinterpret_cast<const f32x4*>(smemB + b_row + j * 16 * SBK + c_hi);
+    pah[0] = *reinterpret_cast<const f32x4*>(smem + a_row + c_hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(smemB + b_row + j * 16 * SBK + c_lo);
+    __builtin_amdgcn_sched_barrier(0);
 
-    int stage = 0, astage = 0;
-    const bool vec = p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0);
-    for (int t = 0; t < ntile; ++t) {
-        const bool has_next = t + 1 < ntile;
-        const float* Anext = has_next ? p.A + (size_t)tile_m0(t + 1) * p.lda : Acur;
-        const float* Bnext = has_next ? p.B + (size_t)tile_n0(t + 1) * p.ldb : Bcur;
-        for (int kt = 0; kt < ktotal; ++kt) {
-            const int astage2 = astage == 0 ? 2 : astage - 1;
+    // ONE loop over the slices of all tiles of this workgroup, two slices per trip (the two B-hi register sets)
+    int stage = 0, astage = 0, kt = 0, t = 0;
+    bool has_next = ntile > 1;
+    const float* Anext = has_next ? p.A + (size_t)tile_m0(1) * p.lda : Acur;
+    const float* Bnext = has_next ? p.B + (size_t)tile_n0(1) * p.ldb : Bcur;
+    const int npair = ntile * (ktotal >> 1);
+    // C of a finished tile (wave-uniform base cb); the accumulators restart from the next tile's bias (or zero)
+    auto store_tile = [&](float* cb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float* c = cb + (coff + i * crow16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<f32x4*>(c + j * 16) = acc[i][j];
+                acc[i][j] = BIAS ? init[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    for (int s = 0; s < npair; ++s) {
+        if (kt == ktotal) {
+            // ---- tile t is complete (checked at the TOP of the trip, so that nothing but the loop edge follows a slice's
+            // tail: the compiler sinks the tail's fragment reads into whatever block comes next) ----
+            store_tile(p.C + (size_t)tile_m0(t) * p.ldc + tile_n0(t));
+            kt = 0;
+            ++t;
+            Acur = Anext; Bcur = Bnext;
+            has_next = t + 1 < ntile;
+            if (has_next) {
+                Anext = p.A + (size_t)tile_m0(t + 1) * p.lda;
+                Bnext = p.B + (size_t)tile_n0(t + 1) * p.ldb;
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int astage1 = astage == 2 ? 0 : astage + 1, astage2 = astage == 0 ? 2 : astage - 1;
             float* dA = smem + astage2 * T4_A + wave * 4 * 8 * SBK;            // A(s+2)
             float* dB = smemB + (stage ^ 1) * T4_A + wave * 4 * 8 * SBK;       // B(s+1)
             // where slices s+1 / s+2 of the stream live: this tile, the next one, or (at the very end) a harmless re-fetch
@@ -713,75 +861,26 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
             const float* Ap = Asrc + (size_t)ka_i * SBK;
             const float* As = smem + astage * T4_A;
             const float* Bs = smemB + stage * T4_A;
-            f32x4 bh[4], bl[4], ah, al, ahn, aln;
-            al = *reinterpret_cast<const f32x4*>(As + a_row + c_lo);
-            bh[0] = *reinterpret_cast<const f32x4*>(Bs + b_row + c_hi);
-            __builtin_amdgcn_sched_barrier(0);
+            const float* Asn = smem + astage1 * T4_A;
+            const float* Bsn = smemB + (stage ^ 1) * T4_A;
+#if WF3D_STAMP
+            if (tid == 0 && 2 * s + half < STAMP_PER_WG) g_stamps[bid * STAMP_PER_WG + 2 * s + half] = __builtin_amdgcn_s_memtime();    // older than this slice's DMA pieces
+#endif
+            if (BIAS && half == 1 && has_next && kt == ktotal - 1) {
+                // the next tile's bias, requested before this slice's DMA pieces: the slice's vmcnt(4) retires it
+                const float* bsrc = p.bias + tile_n0(t + 1) + lane_col;
 #pragma unroll
-            for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + c_hi);
-            __builtin_amdgcn_sched_barrier(0);
-            ah = *reinterpret_cast<const f32x4*>(As + a_row + c_hi);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + c_lo);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i < 7) {
-                    ahn = *reinterpret_cast<const f32x4*>(As + a_row + (i + 1) * 16 * SBK + c_hi);
-                    aln = *reinterpret_cast<const f32x4*>(As + a_row + (i + 1) * 16 * SBK + c_lo);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (i < 4) {      // B(s+1) first, A(s+2) last: the slice-end wait skips exactly the 4 youngest
-                    if (i < 2) { dma16_asm(Bp + boff[2 * i], dB + (2 * i) * 8 * SBK);         dma16_asm(Bp + boff[2 * i + 1], dB + (2 * i + 1) * 8 * SBK); }
-                    else       { dma16_asm(Ap + aoff[2 * i - 4], dA + (2 * i - 4) * 8 * SBK); dma16_asm(Ap + aoff[2 * i - 3], dA + (2 * i - 3) * 8 * SBK); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), val, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), vah, acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                ah = ahn; al = aln;
+                for (int j = 0; j < 4; ++j) init[j] = gload16_asm(bsrc + j * 16);
             }
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            if (half == 0) x16p_slice<BIAS>(acc, bhA, bhB, bl, pah, pal, As, Bs, Asn, Bsn, a_row, b_row, c_hi, c_lo, Ap, Bp, aoff, boff, dA, dB, init);
+            else           x16p_slice<BIAS>(acc, bhB, bhA, bl, pah, pal, As, Bs, Asn, Bsn, a_row, b_row, c_hi, c_lo, Ap, Bp, aoff, boff, dA, dB, init);
             stage ^= 1;
-            astage = astage == 2 ? 0 : astage + 1;
+            astage = astage1;
+            ++kt;
         }
-        // ---- C of tile t (its first slices of tile t+1 are already in LDS / in flight) ----
-        const int m0 = tile_m0(t), n0 = tile_n0(t);
-        const int colw = n0 + wn * 64 + g * 4;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = m0 + wm * 128 + i * 16 + r16;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = colw + j * 16;
-                f32x4 v = acc[i][j];
-                if (p.bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.bias[col + e];
-                }
-                float* c = p.C + (size_t)row * p.ldc + col;
-                if (WF3D_ABLATE == 3 && v[0] != 1234.5f) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }       // timing-only: no C stores
-                if (vec) {
-                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
-                    if (WF3D_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(c));
-                    else *reinterpret_cast<f32x4*>(c) = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) c[e] = p.accumulate ? c[e] + v[e] : v[e];
-                }
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        Acur = Anext; Bcur = Bnext;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
+    store_tile(p.C + (size_t)tile_m0(t) * p.ldc + tile_n0(t));        // the last tile of this workgroup
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
 }
 
 __global__ __launch_bounds__(256) void split_reduce_kernel(const SplitParams p) {
@@ -905,6 +1004,12 @@ extern "C" int wf3d_gemm_split_dma_ok(int M, int N, int K, int lda, int ldb) {
     return M > 0 && N > 0 && K >= SBK && K % SBK == 0 && lda % 4 == 0 && ldb % 4 == 0;
 }
 
+#if WF3D_STAMP
+extern "C" int wf3d_debug_stamps(unsigned long long* dst, size_t n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int ks, per;
@@ -932,10 +1037,12 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     if (variant == 6) {
         static const int persist_on = [] { const char* e = getenv("WF3D_SPLIT_PERSIST"); return e ? atoi(e) : 1; }();
         const int cus = cu_count();
-        if (persist_on && p.ksplit == 1 && M % 256 == 0 && N % 256 == 0 && K / SBK >= 2 && cus >= 8 && cus % 8 == 0 &&
-            p.nbm * p.nbn >= 2 * cus)
-            hipLaunchKernelGGL(gemm_split_x16p_kernel, dim3(cus, 1, 1), dim3(512), 0, st, p);
-        else
+        // persistent form: full tiles, one pass over K, plain (non-accumulating) 16-B stores
+        if (persist_on && p.ksplit == 1 && !accumulate && M % 256 == 0 && N % 256 == 0 && K / SBK >= 2 && K % (2 * SBK) == 0 && cus >= 8 && cus % 8 == 0 &&
+            p.nbm * p.nbn >= 2 * cus && ldc % 4 == 0 && (long)lda * 1024 < (1L << 32) && (long)ldb * 1024 < (1L << 32) && (long)ldc * 1024 < (1L << 32) && ((uintptr_t)C % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0)) {
+            if (bias) hipLaunchKernelGGL(gemm_split_x16p_kernel<true>, dim3(cus, 1, 1), dim3(512), 0, st, p);
+            else      hipLaunchKernelGGL(gemm_split_x16p_kernel<false>, dim3(cus, 1, 1), dim3(512), 0, st, p);
+        } else
             hipLaunchKernelGGL(gemm_split_x16_kernel<false>, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
     } else {
         hipLaunchKernelGGL(gemm_split_dma3_kernel, dim3(p.nbm * p.nbn, 1, p.ksplit), dim3(512), 0, st, p);
