@@ -8,6 +8,6 @@ for rep in 1 2; do
   for arm in "$@"; do
     name=${arm%%:*}; envs=${arm#*:}
     echo "== $name (rep $rep) $envs"
-    ( for kv in $envs; do export "$kv"; done; python3 $R/scripts/bench_gemm.py | grep -E "SPLIT (NT|dgrad)" )
+    ( for kv in $envs; do export "$kv"; done; python3 $R/scripts/bench_gemm.py | grep -E "SPLIT (NT|dgrad|wgrad\(TN)" )
   done
 done

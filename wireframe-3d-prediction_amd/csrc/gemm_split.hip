@@ -532,68 +532,91 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    auto rdA = [&](const float* As, int i, bool lo) -> f32x4 {
+        if (TN && WF3D_ABLATE != 4) return tr_frag16(reinterpret_cast<const char*>(As), lo ? (a_tn[i] ^ 16) : a_tn[i]);
+        return *reinterpret_cast<const f32x4*>(As + a_row + i * 16 * SBK + (lo ? c_lo : c_hi));
+    };
+    auto rdB = [&](const float* Bs, int j, bool lo) -> f32x4 {
+        if (TN && WF3D_ABLATE != 4) return tr_frag16(reinterpret_cast<const char*>(Bs), lo ? (b_tn[j] ^ 16) : b_tn[j]);
+        return *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + (lo ? c_lo : c_hi));
+    };
+    // Same software pipeline across the barrier as the persistent kernel (x16p_slice): the wait + barrier that publish
+    // slice t+1 sit in front of row-tile 7 of slice t, and slice t+1's first fragments (B-hi into the second register
+    // set, A row-tile 0 into pair 0, B-lo behind row-tile 7's B-lo group) are fetched under its twelve MFMAs.
+    f32x4 bhA[4], bhB[4], bl[4], pah[2], pal[2];
+    pal[0] = rdA(smem, 0, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bhA[j] = rdB(smemB, j, false);
+    pah[0] = rdA(smem, 0, false);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bl[j] = rdB(smemB, j, true);
+    __builtin_amdgcn_sched_barrier(0);
+
     int stage = 0, astage = 0;                              // B ring of 2, A ring of 3
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int astage2 = astage == 0 ? 2 : astage - 1;                  // (astage + 2) % 3
+    auto slice = [&](int kt, f32x4 (&bhc)[4], f32x4 (&bhn)[4]) {
+        const int astage1 = astage == 2 ? 0 : astage + 1, astage2 = astage == 0 ? 2 : astage - 1;
         float* dA = smem + astage2 * T4_A + wave * 4 * 8 * SBK;            // A(kt+2)
         float* dB = smemB + (stage ^ 1) * T4_A + wave * 4 * 8 * SBK;       // B(kt+1)
         // branch-free: past the end the DMA re-fetches the last slice into stages nobody reads again
         const size_t ka = (size_t)min(kt + 2, kt1 - 1) * astep, kb = (size_t)min(kt + 1, kt1 - 1) * bstep;
         const float* As = smem + astage * T4_A;
-        const float* Bs = smemB + stage * T4_A;
-        const char* Ac = reinterpret_cast<const char*>(As);
-        const char* Bc = reinterpret_cast<const char*>(Bs);
-        auto rdA = [&](int i, bool lo) -> f32x4 {
-            if (TN && WF3D_ABLATE != 4) return tr_frag16(Ac, lo ? (a_tn[i] ^ 16) : a_tn[i]);
-            return *reinterpret_cast<const f32x4*>(As + a_row + i * 16 * SBK + (lo ? c_lo : c_hi));
-        };
-        auto rdB = [&](int j, bool lo) -> f32x4 {
-            if (TN && WF3D_ABLATE != 4) return tr_frag16(Bc, lo ? (b_tn[j] ^ 16) : b_tn[j]);
-            return *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + (lo ? c_lo : c_hi));
-        };
-        f32x4 bh[4], bl[4], ah, al, ahn, aln;
-        // Reads in the order the MFMAs consume them, pinned: after the barrier both waves of a SIMD are in the
-        // same phase, so whatever the first MFMA waits for is exposed; it needs only the first two reads.
-        al = rdA(0, true);
-        bh[0] = rdB(0, false);
-        __builtin_amdgcn_sched_barrier(0);
+        const float* Asn = smem + astage1 * T4_A;
+        const float* Bsn = smemB + (stage ^ 1) * T4_A;
 #pragma unroll
-        for (int j = 1; j < 4; ++j) bh[j] = rdB(j, false);
-        __builtin_amdgcn_sched_barrier(0);
-        ah = rdA(0, false);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bl[j] = rdB(j, true);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < 7) {
-                ahn = rdA(i + 1, false);
-                aln = rdA(i + 1, true);
-            }
+        for (int i = 0; i < 7; ++i) {
+            pah[(i + 1) & 1] = rdA(As, i + 1, false);
+            pal[(i + 1) & 1] = rdA(As, i + 1, true);
             __builtin_amdgcn_sched_barrier(0);
-            if (i < 4 && WF3D_ABLATE != 1) {          // B(kt+1) first, A(kt+2) last: the slice-end wait skips exactly the 4 youngest
+            if (i < 4 && WF3D_ABLATE != 1) {          // B(kt+1) first, A(kt+2) last: the wait below skips exactly the 4 youngest
                 if (i < 2) { dma16_asm(bsrc[2 * i] + kb, dB + (2 * i) * 8 * SBK);         dma16_asm(bsrc[2 * i + 1] + kb, dB + (2 * i + 1) * 8 * SBK); }
                 else       { dma16_asm(asrc[2 * i - 4] + ka, dA + (2 * i - 4) * 8 * SBK); dma16_asm(asrc[2 * i - 3] + ka, dA + (2 * i - 3) * 8 * SBK); }
             }
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
+            const bf16x8 vah = __builtin_bit_cast(bf16x8, pah[i & 1]), val = __builtin_bit_cast(bf16x8, pal[i & 1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), val, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), val, acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]), vah, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), vah, acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            ah = ahn; al = aln;
         }
         // B(kt+1) and A(kt+1) landed (all but the 4 youngest pieces = A(kt+2)); this wave's reads of the stages done
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        pal[0] = rdA(Asn, 0, true);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bhn[j] = rdB(Bsn, j, false);
+        pah[0] = rdA(Asn, 0, false);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // row-tile 7 (pair 1): B-lo group first, which frees the B-lo registers for the next slice's
+            const bf16x8 vah = __builtin_bit_cast(bf16x8, pah[1]), val = __builtin_bit_cast(bf16x8, pal[1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]), vah, acc[7][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bl[j] = rdB(Bsn, j, true);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), val, acc[7][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bhc[j]), vah, acc[7][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         stage ^= 1;
-        astage = astage == 2 ? 0 : astage + 1;
+        astage = astage1;
+    };
+    const int npair = (kt1 - kt0) >> 1;
+    int kt = kt0;
+    for (int s = 0; s < npair; ++s) {
+        slice(kt, bhA, bhB);
+        slice(kt + 1, bhB, bhA);
+        kt += 2;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
+    if (kt < kt1) slice(kt, bhA, bhB);           // odd count: the tail's fragment reads fetch a stale stage, harmlessly
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
 
     const bool split = p.ksplit > 1;
     const bool vec = split ? (p.N % 4 == 0) : (p.ldc % 4 == 0 && ((uintptr_t)p.C % 16 == 0));
