@@ -6,14 +6,27 @@ oracle element by element, the oracle is run with the HIP forward's own 0/1 deci
 (frozen=...)).  This module reads those decisions off the autograd nodes of a PointCloudToWireframe output dict."""
 
 
-def capture_decisions(out, model, border=5e-7):
+def _sx8_positive(h_s):
+    """ReLU decision of the forward kernel itself, read off the sx8 operand it wrote: h > 0  <=>  its bf16 high part > 0
+    (bf16 keeps fp32's exponent range, so no positive value rounds to zero)."""
+    import torch
+    R, C = h_s.shape
+    planes = h_s.contiguous().view(torch.bfloat16).view(R, C // 8, 16)
+    return (planes[:, :, :8] > 0).reshape(R, C).cpu()
+
+
+def capture_decisions(out, model, border=5e-7, kernel_masks=False):
     """Read the piecewise-constant decisions the HIP forward took (ReLU masks of every LayerNorm+ReLU,
     pool arg-max rows) off the autograd nodes of a PointCloudToWireframe output dict, BEFORE backward.
 
     Returns (frozen dict for oracle.model_forward(frozen=...), n_border): n_border counts activations
     whose LayerNorm output lies within `border` of 0 — there the mask recomputed here could differ from
     the one the kernels take (they evaluate the same fp32 expression in their own order), so a
-    decision-frozen comparison is only meaningful on inputs with n_border == 0."""
+    decision-frozen comparison is only meaningful on inputs with n_border == 0.
+
+    kernel_masks=True: for the per-point layers whose activated output exists as an sx8 operand (bf16x3 mode), the mask
+    is read from that operand instead — the forward kernel's own decision, exact whatever the margin — and those layers
+    do not count towards n_border.  (Batches of thousands of points always contain activations within 5e-7 of 0.)"""
     relu, n_border = {}, 0
 
     def mask(name, z, mu, rs):
@@ -31,7 +44,10 @@ def capture_decisions(out, model, border=5e-7):
     assert type(efn).__name__.startswith("EncoderFn")
     x2, valid, zs, stats, hs, arg_m, arg_u, cnt = efn.saved
     for i, (z, (mu, rs)) in enumerate(zip(zs, stats)):
-        mask(f"encoder.mlp.{4 * i + 1}", z, mu, rs)
+        if kernel_masks and hs[i] is not None:
+            relu[f"encoder.mlp.{4 * i + 1}"] = _sx8_positive(hs[i])
+        else:
+            mask(f"encoder.mlp.{4 * i + 1}", z, mu, rs)
     pooled, f0, s0, f3, s3 = ffn.saved
     mask("encoder.feature_fusion.1", f0, *s0)
     mask("encoder.feature_fusion.4", f3, *s3)

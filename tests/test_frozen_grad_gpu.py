@@ -39,12 +39,21 @@ def _case(seed, B, N, V, counts, din=8):
     return x, torch.tensor(counts), g, cot
 
 
-def _run(precision, B, N, V, counts, din=8):
+# bf16x3 products carry 2^-17 relative error per operand instead of 2^-24.  With the production kernel selection (split
+# GEMMs only where a layer has >= SPLIT_MIN_ROWS rows) the worst gradient element is asserted at TOL_X3; the small cases
+# below FORCE every GEMM of the model onto bf16x3 (SPLIT_MIN_ROWS = 1, down to 3-row operands, no averaging over rows)
+# to exercise those code paths: measured worst element there 2.1e-4 (edge_mlp.0.weight at B=1, N=33, V=3).
+TOL_X3 = 2e-4
+TOL_X3_FORCED = 3e-4
+
+
+def _run(precision, B, N, V, counts, din=8, min_rows=1, kernel_masks=False, draws=32):
     from wf3d import config
     from models.PointCloudToWireframe import PointCloudToWireframe
     old = (config.precision(), config.SPLIT_MIN_ROWS)
     config.set_precision(precision)
-    config.SPLIT_MIN_ROWS = 1
+    if min_rows is not None:
+        config.SPLIT_MIN_ROWS = min_rows
     try:
         torch.manual_seed(20)
         model = PointCloudToWireframe(din, V).to(dev()).set_dropout(0.0)
@@ -54,15 +63,15 @@ def _run(precision, B, N, V, counts, din=8):
             for n, p in model.named_parameters():
                 if p.dim() == 1:
                     p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
-        for seed in range(100, 132):
+        for seed in range(100, 100 + draws):
             x, cnt, gen, _ = _case(seed, B, N, V, counts, din)
             model.zero_grad(set_to_none=True)
             out = model(x.to(dev()), cnt.to(dev()))
-            frozen, n_border = H.capture_decisions(out, model)
+            frozen, n_border = H.capture_decisions(out, model, kernel_masks=kernel_masks)
             if n_border == 0:
                 break
         else:
-            pytest.fail("no borderline-free input found in 32 draws")
+            pytest.fail(f"no borderline-free input found in {draws} draws")
         cot = {k: torch.randn(out[k].shape, generator=gen) for k in ("vertices", "existence_probabilities", "edge_probs")}
         sum((out[k] * cot[k].to(dev())).sum() for k in cot).backward()
         got = {n: p.grad.detach().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None}
@@ -106,7 +115,7 @@ def test_frozen_gradients_bf16x3_measured(B, N, V, counts):
     print(f"bf16x3 frozen-decision gradients (input seed {seed}): worst element-wise errors", [(f"{e:.1e}", n) for e, n in worst[:5]])
     for k, (a, b) in fwd.items():
         assert a < TOL and b < TOL, (k, a, b)
-    bad = [(n, e) for n, e in errs.items() if not e <= 5e-4]
+    bad = [(n, e) for n, e in errs.items() if not e <= TOL_X3_FORCED]
     assert not bad, bad
 
 
@@ -129,7 +138,7 @@ def test_frozen_gradients_shape_sweep(precision, B, N, V, counts):
     fwd, errs, seed = _run(precision, B, N, V, counts)
     for k, (a, b) in fwd.items():
         assert a < TOL and b < TOL, (k, a, b)
-    tol = TOL if precision == "fp32" else 5e-4
+    tol = TOL if precision == "fp32" else TOL_X3_FORCED
     bad = [(n, e) for n, e in errs.items() if not e <= tol]
     assert not bad, (seed, bad)
 
@@ -142,6 +151,26 @@ def test_frozen_gradients_other_input_widths(precision, din):
     fwd, errs, seed = _run(precision, 2, 40, 6, [6, 4], din=din)
     for k, (a, b) in fwd.items():
         assert a < TOL and b < TOL, (k, a, b)
-    tol = TOL if precision == "fp32" else 5e-4
+    tol = TOL if precision == "fp32" else TOL_X3_FORCED
     bad = [(n, e) for n, e in errs.items() if not e <= tol]
     assert not bad, (seed, bad)
+
+
+def test_frozen_gradients_production_kernel_selection():
+    """B=8, N=4096, V=64 with SPLIT_MIN_ROWS at its default: M = 32,768 rows select what the benchmark runs — the
+    persistent 256x256 kernel on the 1024- and 2048-wide layers (>= 512 tiles), the plain 256x256 kernel on the 512-wide
+    ones, the XCD-mapped split-K wgrads with their slab fold, the fused first layer, the 4-way pool at full width.  A batch
+    of this size always holds activations within 5e-7 of 0, so the per-point ReLU decisions are read from the forward
+    kernel's own sx8 operands (exact), the 32-row head layers' are recomputed as before and must be borderline-free."""
+    counts = [64, 33, 2, 7, 50, 64, 12, 40]
+    fwd, errs, seed = _run("bf16x3", 8, 4096, 64, counts, min_rows=None, kernel_masks=True, draws=8)
+    worst = sorted(((e, n) for n, e in errs.items()), reverse=True)
+    print(f"bf16x3, production kernel selection (input seed {seed}): per-tensor worst element-wise errors")
+    for e, n in worst:
+        print(f"    {e:.2e}  {n}")
+    print("forward (max-abs rel, element-wise):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in fwd.items()})
+    for k, (a, b) in fwd.items():
+        assert a < TOL and b < TOL, (k, a, b)
+    assert len(errs) == 76
+    bad = [(n, e) for n, e in errs.items() if not e <= TOL_X3]
+    assert not bad, bad

@@ -334,7 +334,7 @@ def test_edge_head_v256_vs_oracle(precision):
         assert float(probs[s, e:].abs().max()) == 0.0 if e < probs.shape[1] else True
         loss = loss + (p_ref[0] * cot[s, :e].double()).sum()
     loss.backward()
-    tol = 1e-4 if precision == "fp32" else 5e-4          # bf16x3: measured, see DESIGN.md section 2
+    tol = 1e-4 if precision == "fp32" else 2e-4          # bf16x3: measured 7.7e-5 here, 1.1e-4 at worst
     assert H.elem_err(vd.grad.cpu().numpy(), v64.grad.numpy()) < tol
     worst = 0.0
     for n, p in ep.named_parameters():
@@ -469,4 +469,4 @@ def test_input_cloud_gradient_matches_oracle(precision):
     ref = oracle.model_forward(P, x64, counts, V, training=True, frozen=frozen)
     sum((ref[k] * cot[k].double()).sum() for k in cot).backward()
     e = H.elem_err(xd.grad.cpu().numpy(), x64.grad.numpy())
-    assert e < (1e-4 if precision == "fp32" else 5e-4), e
+    assert e < (1e-4 if precision == "fp32" else 2e-4), e

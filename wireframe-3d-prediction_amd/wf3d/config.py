@@ -31,3 +31,10 @@ def set_precision(p):
 # HIP stream next to the dgrad chain (these launches are 15-60 us kernels that fill a fraction of the chip; in one
 # stream each also pays the drain of its predecessor).  WF3D_SIDE_STREAM=0 keeps everything on the current stream.
 SIDE_STREAM = os.environ.get("WF3D_SIDE_STREAM", "1") != "0"
+
+# Edge head, bf16x3 mode: the per-vertex Linears (embed, in_proj, out_proj, Pa / Pb: sum-of-counts rows, 14 GFLOP per
+# cfg2 step) stay on the exact-fp32 MFMA.  Round 2 ran them on bf16x3 through the general GEMM's x3 staging (0.4 % of
+# the step faster); the production-selection frozen-gradient test (tests/test_frozen_grad_gpu.py) then measured 3.2e-4
+# on attention.in_proj_weight against 1.7e-4 with fp32 here — the 2e-4 bound on every gradient element is worth more.
+# WF3D_EDGE_X3=1 restores the x3 path (kept and tested: tests/test_kernels_gpu.py::test_gemm_x3_layouts).
+EDGE_X3 = os.environ.get("WF3D_EDGE_X3", "0") != "0"

@@ -471,7 +471,7 @@ class EdgeFn(torch.autograd.Function):
         za = ops.gemm(cv, P0w, NT, bias=P0b); sa = ops.row_stats(za)
         # per-vertex Linears (sum-of-counts rows): in bf16x3 mode the fp32 operands are split inside the GEMM's
         # staging pass (x3), forward and backward; the K = 3 coordinate products stay exact fp32
-        x3 = precision == "bf16x3"
+        x3 = precision == "bf16x3" and config.EDGE_X3
         zb = ops.gemm(za, P3w, NT, bias=P3b, pro=Pro(ACT_GELU, sa[0], sa[1], P1g, P1b), x3=x3); sb = ops.row_stats(zb)
         f = ops.ln_act_apply(zb, sb[0], sb[1], P4g, P4b, ACT_NONE, drop_p=pf_, seed=sd[0])
         qkv = ops.gemm(f, Aw, NT, bias=Ab, x3=x3)
