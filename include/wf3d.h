@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WF3D_VERSION 102 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended) */
+#define WF3D_VERSION 103 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended); 103: wf3d_set_option */
 
 #define WF3D_OK 0
 #define WF3D_ERR_ARG (-1)
@@ -47,6 +47,14 @@ extern "C" {
 
 int wf3d_version(void);
 const char* wf3d_last_error(void);
+
+/* Process-wide run-time switches (everything else is per call).
+ *   "tn_rounds" (1..8, default 1 or $WF3D_TN_ROUNDS): workgroups per CU that the large weight-gradient launches of
+ *       wf3d_gemm_split_tn are cut into.  1 is fastest on an idle chip; with a collective's kernels holding CUs beside
+ *       the backward pass (data parallel) a launch of one workgroup per CU waits a whole extra
+ *       round for its last workgroup (+67 %), 2 / 4 rounds lose 15 % / 0 % there and cost 2.5 % / 4 % otherwise.
+ * Returns WF3D_OK, or WF3D_ERR_ARG for an unknown name or a value out of range. */
+int wf3d_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------
  * wf3d_gemm — fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMM with a fused

@@ -27,7 +27,27 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"libwf3d.so does not export {n}"
         assert n in _lib.SIGNATURES, f"wf3d/_lib.py has no ctypes signature for {n}"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.wf3d_version() == 102
+    assert lib.wf3d_version() == 103
+
+
+def test_library_exports_nothing_but_the_header():
+    """exported is a subset of declared too: internal cross-file helpers (the LDS-DMA GEMM back end, the MFMA attention
+    kernels, the error formatter) have hidden visibility."""
+    import subprocess
+    from wf3d import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if "wf3d" in ln.lower()}
+    assert exported == set(declared_symbols()), sorted(exported ^ set(declared_symbols()))
+
+
+def test_set_option_validates():
+    from wf3d import _lib
+    lib = _lib.load()
+    assert lib.wf3d_set_option(b"tn_rounds", 2) == 0
+    assert lib.wf3d_set_option(b"tn_rounds", 1) == 0
+    assert lib.wf3d_set_option(b"tn_rounds", 9) == -1 and b"1..8" in lib.wf3d_last_error()
+    assert lib.wf3d_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.wf3d_last_error()
+    assert lib.wf3d_set_option(None, 1) == -1
 
 
 def test_argument_errors_reported_without_gpu():

@@ -140,6 +140,85 @@ def _worker_late(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_asym(rank, world, port, q):
+    """Rank-asymmetric gradient sets: every rank must issue the same sequence of collectives whatever its
+    local gradients look like, and the ranks' .grad must stay identical.
+      (a) a parameter of the EARLY buckets misses its gradient on rank 1 only;
+      (b) a parameter that never had a gradient (tail bucket) gets one on rank 0 only:
+          find_unused=True reduces and writes it back on both ranks; the default mode raises on BOTH ranks in the next
+          finish() instead of letting them drift."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from wf3d import dist as wd
+    wd.init_from_env("cpu")
+
+    def loss(m, X, use_edge=True, use_spatial=False):
+        h = torch.relu(m.encoder["feature_fusion"](torch.relu(m.encoder["mlp"](X))))
+        v = torch.tanh(m.vertex_predictor(h))
+        o = v.square().sum()
+        if use_edge:
+            o = o + m.edge_predictor["used"](v).square().sum()
+        if use_spatial:
+            o = o + m.edge_predictor["spatial_proj"](v).square().sum()
+        return o
+
+    def reference(m, X, **kw):
+        ps = list(m.parameters())
+        gs = torch.autograd.grad(loss(m, X, **kw), ps, allow_unused=True)
+        out = []
+        for g, p_ in zip(gs, ps):
+            g = torch.zeros_like(p_) if g is None else g.clone()
+            dist.all_reduce(g)
+            out.append(g / world)
+        return out
+
+    for mode in (False, True):
+        torch.manual_seed(5)
+        m = Toy()
+        wd.sync_parameters(m)
+        red = wd.GradReducer(m, bucket_mb=1.0, find_unused=mode)
+        torch.manual_seed(31 + rank)
+        X = torch.randn(4, 6)
+        for step in range(3):                                          # warm-up: everything symmetric, buckets get learned
+            m.zero_grad(set_to_none=True)
+            loss(m, X).backward()
+            red.finish()
+        assert len(red._buckets) >= 3, red.bucket_summary()            # the used parameters moved to the early buckets
+        # (a) edge_predictor.used is in an early bucket and misses its gradient on rank 1
+        want = reference(m, X, use_edge=(rank == 0))
+        m.zero_grad(set_to_none=True)
+        loss(m, X, use_edge=(rank == 0)).backward()
+        red.finish()
+        for (n, p_), w in zip(m.named_parameters(), want):
+            if "spatial" in n:
+                assert p_.grad is None
+            else:
+                assert p_.grad is not None and torch.allclose(p_.grad, w, atol=1e-6), (mode, n)
+        # (b) spatial_proj (tail bucket) gets a gradient on rank 0 only
+        want = reference(m, X, use_spatial=(rank == 0))
+        m.zero_grad(set_to_none=True)
+        loss(m, X, use_spatial=(rank == 0)).backward()
+        red.finish()
+        if mode:
+            for (n, p_), w in zip(m.named_parameters(), want):
+                assert p_.grad is not None and torch.allclose(p_.grad, w, atol=1e-6), (mode, n)
+            m.zero_grad(set_to_none=True)
+            loss(m, X).backward()
+            red.finish()                                               # and the job goes on
+        else:
+            m.zero_grad(set_to_none=True)
+            loss(m, X).backward()
+            try:
+                red.finish()
+                raised = False
+            except RuntimeError as e:
+                raised = "find_unused=True" in str(e)
+            assert raised, "the default mode must report a rank-asymmetric gradient on every rank"
+            dist.barrier()                                             # both ranks got here: nobody hangs in a collective
+    q.put((rank, "ok", None))
+    dist.destroy_process_group()
+
+
 def _run2(target):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -160,6 +239,10 @@ def _run2(target):
 
 def test_grad_reducer_late_gradients_and_accumulation_world2_gloo():
     _run2(_worker_late)
+
+
+def test_grad_reducer_rank_asymmetric_gradients_world2_gloo():
+    _run2(_worker_asym)
 
 
 def test_grad_reducer_world2_gloo():

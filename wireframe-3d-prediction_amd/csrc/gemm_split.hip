@@ -18,6 +18,9 @@
 //                                                            wgrad outputs that are not multiples of 256
 //   split_reduce_kernel                                      split-K slab fold
 #include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 
 #include "wf3d_common.h"
 
@@ -51,6 +54,7 @@ struct SplitParams {
     int ksplit, kt_per_split;
     float* slab;
     int nbm, nbn;
+    unsigned* ctl;     // persistent kernel: 8 tile-claim counters (64 B apart, zeroed per launch) + one mailbox word per workgroup
     int zmap;          // x16 kernel, wgrad: 1 = 1-D grid of tiles x ksplit blocks, XCD k owns the split-K ranges z = k (mod 8)
 };
 
@@ -771,14 +775,29 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
     const int wm = wave >> 2, wn = wave & 3;
     const int r16 = lane & 15, g = lane >> 4;
 
+    // Tiles are CLAIMED, not dealt (round 3): the workgroups that share a blockIdx % 8 label (one XCD under round-robin
+    // placement: speed only) draw the tiles of that label's contiguous range from an atomic counter, one tile ahead of
+    // the one they compute.  A workgroup whose CU another stream's kernel holds (a collective) is dispatched late,
+    // finds the range drawn and exits: k busy CUs cost k/256 of the launch instead of a whole extra round (a fixed
+    // tile list per workgroup did: +45-60 %, scripts/bench_contention.py).  Which workgroup computes a tile has no
+    // influence on its value.  The draw is made by one lane; its result reaches the other seven waves through a
+    // mailbox word in global memory (all 160 KB of LDS are operand stages; the very first draw, before any DMA, goes
+    // through LDS): draw in slice 0 of a tile, publish in slice 1, read in slice 2 — each memory operation is older
+    // than its slice's DMA pieces, so the counted waits below are unchanged — first needed in slice ktotal - 2.
     const int nwg = p.nbm * p.nbn;
-    const int bid = blockIdx.x, S = gridDim.x >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int xcnt = xcd < r8 ? q8 + 1 : q8;
-    if (slot >= xcnt) return;
-    const int ntile = (xcnt - slot + S - 1) / S;
-    const int ktotal = p.K / SBK;                                          // even, >= 2 (host-checked)
+    const unsigned xcnt = xcd < r8 ? q8 + 1 : q8;
+    unsigned* const ctr = p.ctl + xcd * 16;
+    unsigned* const mbox = p.ctl + 128 + bid;
+    if (tid == 0) reinterpret_cast<unsigned*>(smem)[0] = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned c0 = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(smem)[0]);
+    __syncthreads();
+    if (c0 >= xcnt) return;
+    int cur = xbase + (int)c0;                                             // tile being computed
+    const int ktotal = p.K / SBK;                                          // even, >= 8 (host-checked)
 
     // per-lane BYTE offsets of the 4 A and 4 B pieces inside a tile (full tiles only: no row clamping; 256 rows x
     // pitch x 4 B < 2^32 is host-checked)
@@ -790,8 +809,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
         aoff[q] = ((unsigned)row * (unsigned)p.lda + chunk) * 4u;
         boff[q] = ((unsigned)row * (unsigned)p.ldb + chunk) * 4u;
     }
-    auto tile_m0 = [&](int t) { return ((xbase + slot + t * S) / p.nbn) * 256; };
-    auto tile_n0 = [&](int t) { return ((xbase + slot + t * S) % p.nbn) * 256; };
+    auto tile_m0 = [&](int id) { return (id / p.nbn) * 256; };
+    auto tile_n0 = [&](int id) { return (id % p.nbn) * 256; };
     // lane (r16, g) of wave (wm, wn) holds C[m0 + wm*128 + i*16 + r16][n0 + wn*64 + j*16 + g*4 .. +3]
     const unsigned crow16 = 16u * (unsigned)p.ldc;
     const int lane_col = wn * 64 + g * 4;
@@ -801,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         init[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (BIAS) init[j] = *reinterpret_cast<const f32x4*>(p.bias + tile_n0(0) + lane_col + j * 16);     // before any DMA: a plain, compiler-counted load
+        if (BIAS) init[j] = *reinterpret_cast<const f32x4*>(p.bias + tile_n0(cur) + lane_col + j * 16);     // before any DMA: a plain, compiler-counted load
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -812,8 +831,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
     const int a_row = (wm * 128 + r16) * SBK, b_row = (wn * 64 + r16) * SBK;
     float* const smemB = smem + 3 * T4_A;
 
-    const float* Acur = p.A + (size_t)tile_m0(0) * p.lda;                  // scalar bases of the current / next tile
-    const float* Bcur = p.B + (size_t)tile_n0(0) * p.ldb;
+    const float* Acur = p.A + (size_t)tile_m0(cur) * p.lda;                // scalar bases of the current / next tile
+    const float* Bcur = p.B + (size_t)tile_n0(cur) * p.ldb;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]) :: "memory");       // the bias loads are done before the counted DMA stream starts
     {   // prologue of the whole stream: A(0), B(0), A(1) of the first tile
         float* dA = smem + wave * 4 * 8 * SBK;
@@ -837,12 +856,12 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
     for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const f32x4*>(smemB + b_row + j * 16 * SBK + c_lo);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ONE loop over the slices of all tiles of this workgroup, two slices per trip (the two B-hi register sets)
-    int stage = 0, astage = 0, kt = 0, t = 0;
-    bool has_next = ntile > 1;
-    const float* Anext = has_next ? p.A + (size_t)tile_m0(1) * p.lda : Acur;
-    const float* Bnext = has_next ? p.B + (size_t)tile_n0(1) * p.ldb : Bcur;
-    const int npair = ntile * (ktotal >> 1);
+    // ONE loop over the slices of all tiles this workgroup draws, two slices per trip (the two B-hi register sets)
+    int stage = 0, astage = 0, kt = 0, nxt = cur;
+    bool has_next = false;                                                 // known from slice 3 of a tile on
+    unsigned drawn = 0;
+    const float* Anext = Acur;
+    const float* Bnext = Bcur;
     // C of a finished tile (wave-uniform base cb); the accumulators restart from the next tile's bias (or zero)
     auto store_tile = [&](float* cb) {
 #pragma unroll
@@ -855,22 +874,40 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
             }
         }
     };
-    for (int s = 0; s < npair; ++s) {
+    int trip = 0;            // (slice counter of the diagnostic stamps)
+    for (;; ++trip) {
         if (kt == ktotal) {
-            // ---- tile t is complete (checked at the TOP of the trip, so that nothing but the loop edge follows a slice's
-            // tail: the compiler sinks the tail's fragment reads into whatever block comes next) ----
-            store_tile(p.C + (size_t)tile_m0(t) * p.ldc + tile_n0(t));
+            // ---- tile `cur` is complete (checked at the TOP of the trip, so that nothing but the loop edge follows a
+            // slice's tail: the compiler sinks the tail's fragment reads into whatever block comes next) ----
+            store_tile(p.C + (size_t)tile_m0(cur) * p.ldc + tile_n0(cur));
+            if (!has_next) break;
             kt = 0;
-            ++t;
+            cur = nxt;
             Acur = Anext; Bcur = Bnext;
-            has_next = t + 1 < ntile;
-            if (has_next) {
-                Anext = p.A + (size_t)tile_m0(t + 1) * p.lda;
-                Bnext = p.B + (size_t)tile_n0(t + 1) * p.ldb;
-            }
+            has_next = false;
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            // The draw for the tile after `cur`: three hidden (inline-asm) memory operations, each issued at the top of
+            // its slice — older than that slice's DMA pieces, so the slice's own vmcnt(4) retires it — and consumed
+            // one slice later behind an empty asm that names the register (no extra wait anywhere; the compiler's
+            // builtins for the same operations wait vmcnt(0) on the spot, draining this wave's pipeline once per tile).
+            if (half == 0 && kt == 0) {
+                if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr), "v"(1u) : "memory");
+            }
+            if (half == 1 && kt == 1) {
+                asm volatile("" : "+v"(drawn));
+                if (tid == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(mbox), "v"(drawn) : "memory");
+            }
+            if (half == 0 && kt == 2) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(drawn) : "v"(mbox) : "memory");
+            if (half == 1 && kt == 3) {
+                asm volatile("" : "+v"(drawn));
+                const unsigned d = __builtin_amdgcn_readfirstlane(drawn);
+                has_next = d < xcnt;
+                nxt = has_next ? xbase + (int)d : cur;
+                Anext = p.A + (size_t)tile_m0(nxt) * p.lda;
+                Bnext = p.B + (size_t)tile_n0(nxt) * p.ldb;
+            }
             const int astage1 = astage == 2 ? 0 : astage + 1, astage2 = astage == 0 ? 2 : astage - 1;
             float* dA = smem + astage2 * T4_A + wave * 4 * 8 * SBK;            // A(s+2)
             float* dB = smemB + (stage ^ 1) * T4_A + wave * 4 * 8 * SBK;       // B(s+1)
@@ -887,11 +924,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
             const float* Asn = smem + astage1 * T4_A;
             const float* Bsn = smemB + (stage ^ 1) * T4_A;
 #if WF3D_STAMP
-            if (tid == 0 && 2 * s + half < STAMP_PER_WG) g_stamps[bid * STAMP_PER_WG + 2 * s + half] = __builtin_amdgcn_s_memtime();    // older than this slice's DMA pieces
+            if (tid == 0 && 2 * trip + half < STAMP_PER_WG) g_stamps[bid * STAMP_PER_WG + 2 * trip + half] = __builtin_amdgcn_s_memtime();    // older than this slice's DMA pieces
 #endif
             if (BIAS && half == 1 && has_next && kt == ktotal - 1) {
                 // the next tile's bias, requested before this slice's DMA pieces: the slice's vmcnt(4) retires it
-                const float* bsrc = p.bias + tile_n0(t + 1) + lane_col;
+                const float* bsrc = p.bias + tile_n0(nxt) + lane_col;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) init[j] = gload16_asm(bsrc + j * 16);
             }
@@ -902,7 +939,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16p_kernel(const SplitPara
             ++kt;
         }
     }
-    store_tile(p.C + (size_t)tile_m0(t) * p.ldc + tile_n0(t));        // the last tile of this workgroup
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup
 }
 
@@ -1033,11 +1069,13 @@ extern "C" int wf3d_debug_stamps(unsigned long long* dst, size_t n) {
 }
 #endif
 
+constexpr size_t CTL_BYTES = 2048;        // persistent kernel: 8 claim counters 64 B apart (512 B, zeroed per launch) + 256+ mailbox words
+
 extern "C" size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int ks, per;
     plan(M, N, K, ks, per);
-    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : CTL_BYTES;
 }
 
 extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N,
@@ -1061,8 +1099,11 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
         static const int persist_on = [] { const char* e = getenv("WF3D_SPLIT_PERSIST"); return e ? atoi(e) : 1; }();
         const int cus = cu_count();
         // persistent form: full tiles, one pass over K, plain (non-accumulating) 16-B stores
-        if (persist_on && p.ksplit == 1 && !accumulate && M % 256 == 0 && N % 256 == 0 && K / SBK >= 2 && K % (2 * SBK) == 0 && cus >= 8 && cus % 8 == 0 &&
+        if (persist_on && p.ksplit == 1 && !accumulate && M % 256 == 0 && N % 256 == 0 && K / SBK >= 8 && K % (2 * SBK) == 0 &&
+            ws != nullptr && ws_bytes >= CTL_BYTES && (uintptr_t)ws % 64 == 0 && cus <= 384 && cus >= 8 && cus % 8 == 0 &&
             p.nbm * p.nbn >= 2 * cus && ldc % 4 == 0 && (long)lda * 1024 < (1L << 32) && (long)ldb * 1024 < (1L << 32) && (long)ldc * 1024 < (1L << 32) && ((uintptr_t)C % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0)) {
+            p.ctl = (unsigned*)ws;
+            if (hipMemsetAsync(ws, 0, 512, st) != hipSuccess) { wf3d_set_error("wf3d_gemm_split_dma: hipMemsetAsync failed"); return WF3D_ERR_LAUNCH; }
             if (bias) hipLaunchKernelGGL(gemm_split_x16p_kernel<true>, dim3(cus, 1, 1), dim3(512), 0, st, p);
             else      hipLaunchKernelGGL(gemm_split_x16p_kernel<false>, dim3(cus, 1, 1), dim3(512), 0, st, p);
         } else
@@ -1084,6 +1125,22 @@ extern "C" int wf3d_gemm_split_tn_ok(int Mo, int No, int K, int lda, int ldb) {
 }
 
 namespace {
+std::atomic<int> g_tn_rounds{[] { const char* e = getenv("WF3D_TN_ROUNDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }()};
+}  // namespace
+
+// Run-time switches (process-wide).  "tn_rounds" = workgroups per CU the 16+-tile wgrad launches are cut into (1..8).
+extern "C" int wf3d_set_option(const char* name, int value) {
+    WF3D_CHECK(name != nullptr, WF3D_ERR_ARG, "wf3d_set_option: null name");
+    if (strcmp(name, "tn_rounds") == 0) {
+        WF3D_CHECK(value >= 1 && value <= 8, WF3D_ERR_ARG, "wf3d_set_option: tn_rounds must be 1..8 (got %d)", value);
+        g_tn_rounds.store(value, std::memory_order_relaxed);
+        return WF3D_OK;
+    }
+    wf3d_set_error("wf3d_set_option: unknown option '%s'", name);
+    return WF3D_ERR_ARG;
+}
+
+namespace {
 // Wgrad kernel choice: 256x256 tiles on the 16x16x32 MFMA when the output allows (WF3D_TN16=0 forces
 // the 256x128 32x32x16 kernel).
 bool tn16(int Mo, int No) {
@@ -1096,8 +1153,15 @@ void plan_tn(int Mo, int No, int K, int& ksplit, int& kt_per) {
     const int ktotal = K / SBK;
     ksplit = 1; kt_per = ktotal;
     if (tiles >= 256 || ktotal < 8) return;
-    // one workgroup per CU either way; the big tile runs one full wave of 256 workgroups
-    int want = (int)(((big ? 256 : 512) + tiles - 1) / tiles);
+    // one workgroup per CU either way; the big tile runs one full wave of 256 workgroups.  WF3D_TN_ROUNDS=f deals f
+    // workgroups per CU (K ranges f times shorter, f times the slabs): a CU held by another stream's kernel then costs
+    // the launch 1/f of its time instead of all of it, at the price of the extra slab traffic.
+    // Measured (scripts/bench_contention.py, scripts/ab_gemm.sh): the 32-tile wgrads (2048 x 1024) pay +2.5 % / +4 % for
+    // f = 2 / 4 on an idle chip and lose 15 % / 0 % instead of 67 % beside a kernel that holds CUs; the 8-tile ones
+    // (already 32 ranges of 2 MB slabs) pay +9 % / +28 %, so f applies from 16 tiles up.  wf3d_set_option("tn_rounds", f);
+    // wf3d.dist turns it on (2) when gradients are reduced beside the backward pass.
+    const int rounds = tiles >= 16 ? g_tn_rounds.load(std::memory_order_relaxed) : 1;
+    int want = (int)(((big ? 256 : 512) * rounds + tiles - 1) / tiles);
     // One or two output tiles (the edge MLP's 128 x 256 and 256 x 512 weights over ~10^5 - 10^6 edge rows) are a streaming
     // reduction over K: they get a K range per CU (up to 256 slabs) as long as a range keeps >= 8 slices; more tiles
     // keep the 64-range cap that bounds the slab traffic (with 64 ranges the 128 x 256 wgrad of cfg5 ran on 64 CUs
@@ -1105,7 +1169,7 @@ void plan_tn(int Mo, int No, int K, int& ksplit, int& kt_per) {
     const bool few = tiles <= 4;
     int ks = want < ktotal / (few ? 8 : 4) ? want : ktotal / (few ? 8 : 4);
     static const int few_cap = [] { const char* e = getenv("WF3D_TN_FEW_CAP"); return e ? atoi(e) : 256; }();
-    const int cap = few ? few_cap : 64;
+    const int cap = few ? few_cap : 64 * rounds;
     if (ks > cap) ks = cap;
     if (few && ks >= 8) ks &= ~7;                 // multiples of 8: the XCD-mapped launch order applies
     if (ks < 2) return;

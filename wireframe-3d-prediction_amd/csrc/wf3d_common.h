@@ -11,8 +11,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define WF3D_WAVE 64
 
+// Internal cross-translation-unit helpers are not part of the C ABI: hidden, so that libwf3d.so exports exactly what
+// include/wf3d.h declares (tests/test_capi_symbols.py checks both directions).
+#define WF3D_INTERNAL __attribute__((visibility("hidden")))
+
 // ---- error plumbing (host) -------------------------------------------------
-void wf3d_set_error(const char* fmt, ...);
+WF3D_INTERNAL void wf3d_set_error(const char* fmt, ...);
 #define WF3D_CHECK(cond, code, ...)                \
     do {                                           \
         if (!(cond)) {                             \
@@ -31,16 +35,16 @@ void wf3d_set_error(const char* fmt, ...);
     } while (0)
 
 // internal (not part of include/wf3d.h): LDS-DMA variant of the split GEMM, gemm_split.hip
-extern "C" int wf3d_gemm_split_dma_ok(int M, int N, int K, int lda, int ldb);
-extern "C" size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K);
-extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N,
+extern "C" WF3D_INTERNAL int wf3d_gemm_split_dma_ok(int M, int N, int K, int lda, int ldb);
+extern "C" WF3D_INTERNAL size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K);
+extern "C" WF3D_INTERNAL int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* C, const float* bias, int M, int N,
                                    int K, int lda, int ldb, int ldc, int accumulate, void* ws, size_t ws_bytes,
                                    void* stream);
 
 // internal: MFMA attention for head_dim 64 (attn_mfma.hip)
-extern "C" int wf3d_attn_fwd_mfma(const float* qkv, const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
+extern "C" WF3D_INTERNAL int wf3d_attn_fwd_mfma(const float* qkv, const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
                                   uint32_t drop_seed, float* ctx, float* lse, void* stream);
-extern "C" int wf3d_attn_bwd_mfma(const float* qkv, const float* dctx, const float* ctx, const float* lse,
+extern "C" WF3D_INTERNAL int wf3d_attn_bwd_mfma(const float* qkv, const float* dctx, const float* ctx, const float* lse,
                                   const int32_t* voff, int S, int vmax, int E, int heads, float drop_p,
                                   uint32_t drop_seed, float* dqkv, void* stream);
 

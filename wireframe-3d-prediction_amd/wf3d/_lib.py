@@ -78,6 +78,7 @@ class SkinnyRed(ctypes.Structure):
 SIGNATURES = {
     "wf3d_version": (c_int, []),
     "wf3d_last_error": (ctypes.c_char_p, []),
+    "wf3d_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "wf3d_gemm_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "wf3d_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "wf3d_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -69,28 +69,45 @@ def _stage_of(name):
 class GradReducer:
     """Bucketed, overlapped gradient averaging.
 
-    usage:   red = GradReducer(model);  loss.backward();  red.finish()      (one backward per finish)
-    Buckets follow backward order; a bucket's all-reduce starts from a
-    post-accumulate-grad hook when the last of the parameters that are EXPECTED to receive a
-    gradient has received its own, on the communication stream of the process group (async_op),
-    and `finish()` waits and scatters the averaged values back into `.grad`.
+    usage:   red = GradReducer(model);  loss.backward();  red.finish()      (any number of backward() calls per finish())
 
-    Expected = every parameter that has ever received a gradient (learned; parameters that never do —
-    EdgePredictor.spatial_proj, SURVEY §9 Q2 — must not hold a bucket back).  A gradient that lands
-    AFTER its bucket was launched (a parameter receiving its first gradient, or a second backward before
-    finish()) marks the bucket stale: finish() then waits for the in-flight reduce and reduces that
-    bucket again from the final .grad values, so nothing stale is ever written back.
+    Every rank issues the SAME sequence of collectives whatever its local gradients look like (a collective is matched by
+    its position in that sequence, so a rank-local decision to issue one more, or to issue two in another order, hangs the
+    job or pairs the wrong buffers):
+      * early buckets hold the parameters that are known — collectively — to receive gradients, in backward order
+        (edge head -> vertex head -> fusion -> per-point MLP).  A bucket's all-reduce is launched from a
+        post-accumulate-grad hook once all its gradients have landed AND every earlier bucket has been launched;
+        whatever was not launched by the end of backward is launched by finish(), in the same order, with zeros in
+        place of a missing gradient.  A second gradient for a parameter whose bucket is already in flight (gradient
+        accumulation: the program does that on every rank alike) marks the bucket for one more reduce in finish().
+      * every other parameter (never seen with a gradient: EdgePredictor.spatial_proj; a lazily
+        created layer in its first steps) sits in the TAIL bucket, reduced by finish() after backward — never stale —
+        together with one flag per parameter, "this rank has a gradient".  The summed flags tell every rank the same
+        thing: a count of `world` promotes the parameter to the early buckets (from the next step on), a count strictly
+        between 0 and `world` is a rank-asymmetric gradient.
+      * find_unused=False (default): the summed flags are copied to the host asynchronously and looked at in the NEXT
+        finish() (no host sync in the step); a rank-asymmetric count raises there, on every rank at once.  Averages are
+        written back wherever a local .grad exists (early buckets: always, a missing .grad is created).
+      * find_unused=True: the flags are read in the same finish() (one small host sync per step) and the averaged value
+        is written into .grad — created where it is None — for every parameter that ANY rank had a gradient for, so the
+        ranks' optimizers stay in step even when their gradient sets differ.
     `exposed_ms()` = time the compute stream spent inside finish() (un-overlapped communication)."""
 
-    def __init__(self, module, bucket_mb=48.0, group=None, average=True):
-        self.module, self.group, self.average = module, group, average
+    def __init__(self, module, bucket_mb=48.0, group=None, average=True, find_unused=False):
+        self.module, self.group, self.average, self.find_unused = module, group, average, find_unused
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.bucket_bytes = int(bucket_mb * (1 << 20))
-        self._buckets = None
+        self._buckets, self._tail = None, None
         self._hooks = []
-        self._ever = set()               # parameters that have received a gradient at least once
+        self._expected = set()           # parameters every rank has had a gradient for (learned from the summed flags)
+        self._pending = None             # (host flags, event, tail params) of the previous finish(), default mode
         self._events = []
         self._build()
+        if self.world > 1 and torch.cuda.is_available():
+            # the reduces run beside the backward pass: cut the large wgrad launches into two rounds of workgroups so a
+            # CU the collective's kernels hold costs them 15 % instead of 67 % (include/wf3d.h, wf3d_set_option)
+            from . import _lib
+            _lib.load().wf3d_set_option(b"tn_rounds", int(os.environ.get("WF3D_TN_ROUNDS", "2")))
 
     def _build(self):
         for h in self._hooks:
@@ -101,6 +118,8 @@ class GradReducer:
         buckets, cur, cur_bytes, cur_stage = [], [], 0, None
         for i in order:
             n, p = named[i]
+            if p not in self._expected:
+                continue
             st = _stage_of(n)
             nbytes = p.numel() * p.element_size()
             if cur and (cur_bytes + nbytes > self.bucket_bytes or st != cur_stage):
@@ -116,74 +135,148 @@ class GradReducer:
         for bi, ps in enumerate(buckets):
             flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
             self._buckets.append({"params": ps, "flat": flat, "got": set(), "work": None, "launched": False,
-                                  "stale": False, "views": None})
+                                  "stale": False, "views": self._views(flat, ps)})
             for p in ps:
                 self._owner[p] = bi
+        tail = [named[i][1] for i in order if named[i][1] not in self._expected]
+        if tail:
+            flat = torch.zeros(sum(p.numel() for p in tail) + len(tail), dtype=tail[0].dtype, device=tail[0].device)
+            self._tail = {"params": tail, "flat": flat, "work": None, "views": self._views(flat, tail),
+                          "flags": flat[flat.numel() - len(tail):]}
+        else:
+            self._tail = None
+        self._next = 0
         self._n_params = len(named)
         if self.world > 1:
             for _, p in named:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                if p in self._owner:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _expected(self, b):
-        exp = [p for p in b["params"] if p in self._ever]
-        return exp if exp else b["params"]          # first step: nothing learned yet -> wait for everything
-
-    def _on_grad(self, p):
-        bi = self._owner.get(p)
-        if bi is None:
-            return
-        b = self._buckets[bi]
-        if b["launched"] or p in b["got"]:
-            b["stale"] = True                       # a gradient after the launch / a second backward: redo in finish()
-        b["got"].add(p)
-        if not b["launched"] and all(q in b["got"] for q in self._expected(b)):
-            self._launch(b)
-
-    def _launch(self, b):
-        flat, off = b["flat"], 0
-        views = []
-        for p in b["params"]:
+    @staticmethod
+    def _views(flat, ps):
+        views, off = [], 0
+        for p in ps:
             n = p.numel()
             views.append(flat[off:off + n].view_as(p))
             off += n
+        return views
+
+    def _on_grad(self, p):
+        b = self._buckets[self._owner[p]]
+        if b["launched"] or p in b["got"]:
+            b["stale"] = True                       # a second gradient (accumulation): one more reduce in finish()
+        b["got"].add(p)
+        self._launch_ready()
+
+    def _launch_ready(self):
+        # strictly in bucket order: the same sequence of collectives on every rank
+        while self._next < len(self._buckets):
+            b = self._buckets[self._next]
+            if not all(q in b["got"] for q in b["params"]):
+                return
+            self._launch(b)
+            self._next += 1
+
+    def _launch(self, b):
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
-        torch._foreach_copy_(views, grads)
-        b["views"] = views
-        b["work"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        torch._foreach_copy_(b["views"], grads)
+        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         b["launched"] = True
 
+    def _consume_pending(self):
+        """Default mode: the summed tail flags of the PREVIOUS finish() (their device-to-host copy has long finished)."""
+        if self._pending is None:
+            return
+        host, ev, params = self._pending
+        self._pending = None
+        if ev is not None:
+            ev.synchronize()
+        self._apply_flags(host.tolist(), params, strict=True)
+
+    def _apply_flags(self, counts, params, strict):
+        promote = []
+        for c, p in zip(counts, params):
+            c = int(round(c))
+            if c == self.world or (c > 0 and not strict):
+                promote.append(p)
+            elif c != 0:
+                raise RuntimeError(
+                    f"wf3d.dist.GradReducer: a parameter of shape {tuple(p.shape)} received a gradient on {c} of {self.world} "
+                    "ranks in the previous step.  The ranks' gradient sets differ; construct GradReducer(..., "
+                    "find_unused=True), which reduces and writes back such gradients exactly (one small host sync per step).")
+        if promote:
+            self._expected.update(promote)
+            self._dirty = True
+
     def finish(self):
-        """Wait for all buckets (launching any whose hooks did not all fire, e.g.
-        parameters without a gradient this step) and write averages into .grad."""
+        """Launch what the hooks have not (in order), redo buckets that accumulated a second gradient, reduce the tail
+        bucket with its flags, wait, and write the averages into .grad."""
         if self.world == 1:
             return
-        timed = torch.cuda.is_available() and self._buckets and self._buckets[0]["flat"].is_cuda
+        timed = torch.cuda.is_available() and any(p.is_cuda for p in self.module.parameters())
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        self._dirty = False
+        self._consume_pending()
         n = sum(1 for p in self.module.parameters() if p.requires_grad)
-        if n != self._n_params:                     # a lazy parameter appeared: drain, re-bucket, reduce everything now
+        if n != self._n_params:                     # a lazy parameter appeared: drain, re-bucket (it starts in the tail)
             for b in self._buckets:
                 if b["work"] is not None:
                     b["work"].wait()
+                    b["launched"] = False
             self._build()
-        for b in self._buckets:
-            if b["launched"] and b["stale"]:
-                b["work"].wait()                    # the early reduce carried stale values: do it again
-                b["launched"] = False
-            if not b["launched"]:
+        for b in self._buckets[self._next:]:        # first round, same order as the hooks would have used
+            self._launch(b)
+        self._next = len(self._buckets)
+        for b in self._buckets:                     # accumulation: the early reduce carried a partial sum
+            if b["stale"]:
+                b["work"].wait()
                 self._launch(b)
+        t = self._tail
+        if t is not None:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in t["params"]]
+            torch._foreach_copy_(t["views"], grads)
+            t["flags"].copy_(torch.tensor([0.0 if p.grad is None else 1.0 for p in t["params"]], dtype=t["flat"].dtype))
+            t["work"] = dist.all_reduce(t["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         scale = 1.0 / self.world if self.average else 1.0
         for b in self._buckets:
             b["work"].wait()
             if scale != 1.0:
                 b["flat"].mul_(scale)
-            dst = [p.grad for p in b["params"] if p.grad is not None]
-            src = [v for p, v in zip(b["params"], b["views"]) if p.grad is not None]
-            if dst:
-                torch._foreach_copy_(dst, src)
-            self._ever.update(p for p in b["params"] if p.grad is not None)
+            for p, v in zip(b["params"], b["views"]):
+                if p.grad is None:
+                    p.grad = v.clone()              # a parameter of the early buckets missed its gradient on this rank
+            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
             b["got"], b["work"], b["launched"], b["stale"] = set(), None, False, False
+        self._next = 0
+        if t is not None:
+            t["work"].wait()
+            t["work"] = None
+            nvals = t["flat"].numel() - len(t["params"])
+            if scale != 1.0:
+                t["flat"][:nvals].mul_(scale)
+            if self.find_unused:
+                counts = t["flags"].cpu().tolist()   # the one host sync of this mode
+                for c, p, v in zip(counts, t["params"], t["views"]):
+                    if c > 0.5:
+                        if p.grad is None:
+                            p.grad = v.clone()
+                        else:
+                            p.grad.copy_(v)
+                self._apply_flags(counts, t["params"], strict=False)
+            else:
+                pairs = [(p.grad, v) for p, v in zip(t["params"], t["views"]) if p.grad is not None]
+                if pairs:
+                    torch._foreach_copy_([a for a, _ in pairs], [b_ for _, b_ in pairs])
+                host = t["flags"].to("cpu", non_blocking=True)
+                ev = None
+                if t["flags"].is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self._pending = (host, ev, list(t["params"]))
+        if self._dirty:
+            self._build()                           # promoted parameters move to the early buckets from the next step on
         if timed:
             e1.record()
             self._events.append((e0, e1))
@@ -200,4 +293,7 @@ class GradReducer:
         return out
 
     def bucket_summary(self):
-        return [(len(b["params"]), b["flat"].numel() * b["flat"].element_size()) for b in self._buckets]
+        out = [(len(b["params"]), b["flat"].numel() * b["flat"].element_size()) for b in self._buckets]
+        if self._tail is not None:
+            out.append((len(self._tail["params"]), self._tail["flat"].numel() * self._tail["flat"].element_size()))
+        return out
