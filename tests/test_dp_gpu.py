@@ -60,7 +60,7 @@ def _worker(rank, world, port, B, N, V, q):
     red = wd.GradReducer(model)
     x, counts, cot = _inputs(B, N, V)
     lo, hi = wd.shard_batch(B, rank, world)
-    for step in range(2):                            # second step exercises the learned `expect` counts
+    for step in range(4):                            # steps 3 and 4 run with the learned early buckets (hook-launched reduces)
         model.zero_grad(set_to_none=True)
         _run(model, x[lo:hi], counts[lo:hi], {k: v[lo:hi] for k, v in cot.items()}, dev, 1.0 / (hi - lo))
         red.finish()
@@ -71,6 +71,35 @@ def _worker(rank, world, port, B, N, V, q):
         q.put({n: p.detach().cpu().numpy() for n, p in model.named_parameters()})
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+
+def _check_dp_gradients(named_params, grads):
+    """Two ranks' averaged gradients against the whole batch in one process, per tensor.  The two runs partition the rows
+    of every GEMM differently, so a handful of ReLU decisions on activations that are 0 to within an ulp may differ
+    (isolated elements, whole-row contributions): an L2 bound has to leave room for them and would then also pass a 1e-3
+    error in the loss renormalisation (WireframeLoss.set_data_parallel) or in the 1/world scale.  Such an error is a common
+    FACTOR on a tensor, so it is tested as one: the least-squares scale alpha = <g_dp, g_ref> / <g_ref, g_ref> must be 1
+    to 2e-5 for every tensor (measured 2e-7), and all but 1 % of a tensor's elements must agree to 1e-4 of max(|g_ref|, rms)."""
+    worst_alpha, worst_frac, worst_l2 = 0.0, 0.0, 0.0
+    for n, p in named_params:
+        if p.grad is None:
+            assert n not in grads
+            continue
+        a, b = torch.from_numpy(grads[n]).double().flatten(), p.grad.detach().cpu().double().flatten()
+        bb = float(b @ b)
+        if bb == 0.0:
+            assert float(a.abs().max()) == 0.0, n
+            continue
+        alpha = float(a @ b) / bb
+        rms = (bb / b.numel()) ** 0.5
+        frac = float(((a - b).abs() > 1e-4 * torch.clamp(b.abs(), min=rms)).double().mean())
+        l2 = float((a - b).norm() / b.norm())
+        worst_alpha, worst_frac, worst_l2 = max(worst_alpha, abs(alpha - 1.0)), max(worst_frac, frac), max(worst_l2, l2)
+        assert abs(alpha - 1.0) < 2e-5, (n, alpha)
+        assert frac < 0.01, (n, frac)
+        assert l2 < 2e-3, (n, l2)
+    print(f"DP vs single process: worst |alpha - 1| {worst_alpha:.1e}, worst share of elements off by > 1e-4 {worst_frac:.1e}, worst L2 {worst_l2:.1e}")
 
 
 def test_two_rank_gradients_equal_single_process_batch():
@@ -97,14 +126,7 @@ def test_two_rank_gradients_equal_single_process_batch():
     x, counts, cot = _inputs(B, N, V)
     # mean over the two shards of (shard loss / shard size) == whole-batch loss / B for equal shards
     _run(model, x, counts, cot, dev, 1.0 / B)
-    worst = 0.0
-    for n, p in model.named_parameters():
-        if p.grad is None:
-            assert n not in grads
-            continue
-        a, b = torch.from_numpy(grads[n]).double(), p.grad.detach().cpu().double()
-        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
-    assert worst < 2e-3, worst
+    _check_dp_gradients(list(model.named_parameters()), grads)
 
 
 # ---------------------------------------------------------------------------
@@ -186,11 +208,4 @@ def test_two_rank_real_loss_with_ragged_counts_equals_single_process():
     crit = WireframeLoss(vertex_weight=3.0, edge_weight=1.0, existence_weight=1.5)
     res = _loss_step(model, crit, x, counts, tg, dev, slice(0, B))
     assert abs(float(res["total_loss"]) - mean_total) < 1e-5 * max(1.0, abs(mean_total)), (float(res["total_loss"]), mean_total)
-    worst = 0.0
-    for n, p in model.named_parameters():
-        if p.grad is None:
-            assert n not in grads
-            continue
-        a, b = torch.from_numpy(grads[n]).double(), p.grad.detach().cpu().double()
-        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
-    assert worst < 2e-3, worst
+    _check_dp_gradients(list(model.named_parameters()), grads)
