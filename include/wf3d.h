@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WF3D_VERSION 103 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended); 103: wf3d_set_option */
+#define WF3D_VERSION 104 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended); 103: wf3d_set_option; 104: wf3d_edge_pair_ln_bwd, wf3d_edge_pair_fwd_ln accepts pre = NULL */
 
 #define WF3D_OK 0
 #define WF3D_ERR_ARG (-1)
@@ -348,11 +348,24 @@ int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const 
                        const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
                        float* pre, float* mu, float* rs, float* delta, void* stream);
 /* Same, and also h = drop(act(LayerNorm(pre))) as the sx8 operand of the next Linear (edge_mlp[1..4] of
- * EdgePredictor.py:57-60) from the row the wave still holds: saves wf3d_ln_prep's second read of pre. */
+ * EdgePredictor.py:57-60) from the row the wave still holds: saves wf3d_ln_prep's second read of pre.
+ * pre may be NULL: the pre-activation is then not stored at all (2 KB per edge row at hidden 512) and the backward
+ * rebuilds it from Pa / Pb with wf3d_edge_pair_ln_bwd below. */
 int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
                           const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
                           float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
                           float drop_p, uint32_t drop_seed, void* h_sx8, void* stream);
+/* LayerNorm / activation backward of that first edge layer with its pre-activation REBUILT, not read:
+ * pre[e, :] = Pa[i, :] + Pb[j, :] + delta[e] * wdelta (the expression the forward kernel evaluated) from the per-vertex
+ * tables, which stay L2-resident (V x H per sample).  dh [Re, H] -> dz (may alias dh), dgamma / dbeta (one [2][H]
+ * buffer) and wsum[c] = sum_e dz[e, c] * delta[e], the gradient of the distance column of edge_mlp[0].weight
+ * (EdgePredictor.py:130-137).  Same arithmetic as wf3d_ln_act_bwd_wsum on a stored pre. */
+size_t wf3d_edge_pair_ln_bwd_ws_bytes(int Re, int H);
+int wf3d_edge_pair_ln_bwd(const float* dh, const float* Pa, const float* Pb, const float* delta, const float* wdelta,
+                          int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H,
+                          const float* mu, const float* rs, const float* gamma, const float* beta, int act, float drop_p,
+                          uint32_t drop_seed, float* dz, float* dgamma, float* dbeta, float* wsum, void* ws, size_t ws_bytes,
+                          void* stream);
 /* dPa[v] / dPb[v] = segmented sums of dpre over the edges where v is i / j, and
  * dcv[v] = sum over incident edges of (dpre[e]·wdelta)(c_v - c_other)/delta[e]
  *          (+ dPa[v]·Wc + dPb[v]·Wd when wcoord != NULL: wcoord[c * wcoord_stride + 0..5] = [Wc[c, :] | Wd[c, :]], the

@@ -160,7 +160,24 @@ with open(os.path.join(P, f"{tag}_summary.md"), "w") as f:
         for n, e in mfma.items():
             f.write(f"* `{n}`: {e['launches']} launches, busy fraction {e['mfma_busy_frac']:.3f}, effective clock "
                     f"{e['effective_clock_ghz']:.2f} GHz (GRBM_GUI_ACTIVE / 8 / wall)\n")
-    top = sorted(((e.get("avg_us", 0.0) * e.get("launches", 0), n, e) for n, e in per_kernel.items()), reverse=True)[:24]
+    # ---- whole step: bytes beyond L2 against the algorithmic minimum ----
+    PASS_STEPS = 2                                   # the byte passes run `--steps 1 --warmup 1`
+    tot_rd = sum(2 * 1024 * v for k in fetch.values() for v, _, _ in k.get("FETCH_SIZE", [])) / PASS_STEPS
+    tot_wr = sum(1024 * v for k in write.values() for v, _, _ in k.get("WRITE_SIZE", [])) / PASS_STEPS
+    Bc, Nc, Vc = {"cfg2": (32, 4096, 64), "cfg4": (8, 16384, 64), "cfg5": (32, 4096, 256)}[cfg]
+    act = Bc * Nc * (8 + 512 + 1024 + 2048 + 1024) * 4          # pre-activations kept for backward, fp32
+    pf = Bc * Nc * 512 * 4                                      # point_features (returned by PointNetEncoder.forward)
+    alg = 2 * act + 2 * pf + 3 * 124.2e6                        # written once + read once; parameters fwd + bwd + gradient write
+    if tot_rd or tot_wr:
+        summary["whole_step"] = {"read_bytes": tot_rd, "write_bytes": tot_wr, "algorithmic_bytes": alg,
+                                 "ratio": (tot_rd + tot_wr) / alg}
+        json.dump(summary, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
+        f.write(f"\n## whole step: bytes beyond L2\n\nsum over all kernels of FETCH_SIZE x 2 + WRITE_SIZE = {tot_rd / 1e9:.1f} + {tot_wr / 1e9:.1f} = "
+                f"**{(tot_rd + tot_wr) / 1e9:.1f} GB per step**; algorithmic minimum with stored pre-activations (SURVEY.md section 8d: "
+                f"2 x {act / 1e9:.2f} GB activations + 2 x {pf / 1e9:.2f} GB point_features + 3 x 0.124 GB parameters) = {alg / 1e9:.1f} GB "
+                f"-> ratio {(tot_rd + tot_wr) / alg:.1f}x\n")
+    top = sorted(((e.get("avg_us", 0.0) * e.get("launches", 0), n, e) for n, e in per_kernel.items()), reverse=True)
+    top = [t for t in top if t[0] > 0.0]             # every kernel that ran (no cut: cfg5 must show the attention kernels)
     if top:
         f.write("\n## per kernel: MFMA pipe occupancy (SQ pass) and HBM-side bytes per launch (FETCH_SIZE x 2 x 1 KiB, WRITE_SIZE x 1 KiB; own passes)\n\n")
         f.write("| kernel | launches | avg us | MFMA busy | clock GHz | read MB | write MB | GB/s |\n|---|---|---|---|---|---|---|---|\n")

@@ -495,6 +495,28 @@ def test_rowdot_logits_layer_forward_and_fused_backward(ops, R, D):
     assert not ops.rowdot_act_ok(rnd(8, 24, seed=5), rnd(1, 24, seed=6))       # 24/8 = 3 lanes per row: not a power of two
 
 
+@pytest.mark.parametrize("H,counts,drop", [(512, [9, 2, 5], 0.0), (64, [4, 7], 0.0), (512, [6, 6], 0.1), (1024, [3, 8], 0.0),
+                                           (512, [40, 2, 17, 33], 0.0)])
+def test_pair_ln_backward_without_the_stored_preactivation(ops, H, counts, drop):
+    """edge_pair_fwd(keep_pre=False) + edge_pair_ln_bwd (pre rebuilt from Pa / Pb in the backward kernel) against the
+    stored-pre path (edge_pair_fwd + ln_act_bwd_wsum on it): the same kernel body on the same floats — bit-identical dz,
+    column sums to rounding — and the forward side writes the same statistics and the same operand h."""
+    meta = ops.EdgeMeta(counts, dev())
+    Pa, Pb = rnd(meta.Rv, H, seed=1), rnd(meta.Rv, H, seed=2)
+    cv = rnd(meta.Rv, 3, seed=3)
+    W0 = rnd(H, 2 * H + 7, seed=4, scale=0.2)
+    gamma, beta = 1.0 + 0.1 * rnd(H, seed=5), 0.1 * rnd(H, seed=6)
+    ln = (gamma, beta, ops.ACT_GELU, drop, 1234)
+    pre, mu, rs, delta, h = ops.edge_pair_fwd(Pa, Pb, cv, W0, meta, ln=ln)
+    none, mu2, rs2, delta2, h2 = ops.edge_pair_fwd(Pa, Pb, cv, W0, meta, ln=ln, keep_pre=False)
+    assert none is None and torch.equal(mu, mu2) and torch.equal(rs, rs2) and torch.equal(delta, delta2) and torch.equal(h, h2)
+    dh = rnd(meta.Re, H, seed=7)
+    dz, dg, db, wsum = ops.ln_act_bwd_wsum(dh.clone(), pre, delta, mu, rs, gamma, beta, ops.ACT_GELU, drop, 1234)
+    dz2, dg2, db2, wsum2 = ops.edge_pair_ln_bwd(dh.clone(), Pa, Pb, delta, W0, meta, mu, rs, gamma, beta, ops.ACT_GELU, drop, 1234)
+    assert torch.equal(dz, dz2)
+    assert rel(dg2, dg) < 1e-6 and rel(db2, db) < 1e-6 and rel(wsum2, wsum) < 1e-6
+
+
 @pytest.mark.parametrize("R,D,drop", [(777, 512, 0.0), (100, 64, 0.1), (300, 1024, 0.0), (64, 2048, 0.0)])
 def test_ln_act_bwd_with_weighted_column_sum(ops, R, D, drop):
     """ln_act_bwd_wsum == ln_act_bwd, plus wsum == colsum(dz, wrow) without the second pass."""

@@ -15,19 +15,6 @@
 
 namespace {
 
-// edge index e (lexicographic i<j over v vertices) -> (i, j)
-__device__ __forceinline__ void edge_ij(int e, int v, int& i, int& j) {
-    const float b = (float)(2 * v - 1);
-    int ii = (int)floorf((b - sqrtf(fmaxf(b * b - 8.0f * (float)e, 0.f))) * 0.5f);
-    ii = max(0, min(ii, v - 2));
-    // offset(i) = i*(2v-i-1)/2 ; fix up float rounding
-    while (ii + 1 <= v - 2 && ((ii + 1) * (2 * v - ii - 2)) / 2 <= e) ++ii;
-    while (ii > 0 && (ii * (2 * v - ii - 1)) / 2 > e) --ii;
-    i = ii;
-    j = e - (ii * (2 * v - ii - 1)) / 2 + ii + 1;
-}
-__device__ __forceinline__ int edge_offset(int i, int v) { return (i * (2 * v - i - 1)) / 2; }
-
 // ---- vertex rows: gather counts[s] leading vertices of each sample ------------
 __global__ __launch_bounds__(256) void gather_verts_kernel(const float* __restrict__ verts, long s_stride, long v_stride,
                                                             const int32_t* __restrict__ voff,
@@ -108,7 +95,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
                     val[t][k] = pa[t][k] + b[k] + dl * wdv[t][k];
                     sum += val[t][k];
                 }
-                *reinterpret_cast<f32x4*>(pre + (size_t)e * H + c) = val[t];
+                if (pre) *reinterpret_cast<f32x4*>(pre + (size_t)e * H + c) = val[t];
             }
         }
         pa_row = ri;
@@ -363,7 +350,7 @@ static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, cons
     WF3D_CHECK(Re >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_fwd: bad dims");
     WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_fwd: hidden %d must be a multiple of 4, <= 2048", H);
     if (Re == 0) return WF3D_OK;
-    WF3D_CHECK(Pa && Pb && cv && wdelta && voff && eoff && esample && pre && mu && rs && delta, WF3D_ERR_ARG,
+    WF3D_CHECK(Pa && Pb && cv && wdelta && voff && eoff && esample && (pre || h_sx8) && mu && rs && delta, WF3D_ERR_ARG,
                "wf3d_edge_pair_fwd: null pointer");
     const int ns = wf3d_cdiv(H, 256);
     hipStream_t st = (hipStream_t)stream;

@@ -83,14 +83,24 @@ __global__ __launch_bounds__(256) void ln_act_apply_kernel(const float* __restri
 // dW[c, k] = sum_r dz[r, c] * x[r, k] is K more weighted column sums of the dz this kernel already holds in
 // registers, so they are accumulated here ([3 + KX][D] partials) and dz itself — which nothing else needs, the
 // input cloud takes no gradient — is never written.
-template <int NS, int WPR, int KX = 0>
+// PAIR (first edge layer, KX = 1 with x0 = |c_i - c_j| per edge row): the pre-activation row is not read but REBUILT,
+// z[e, :] = Pa[i, :] + Pb[j, :] + |c_i - c_j| * w_dist — the expression pair_fwd_kernel evaluated — from the two per-vertex
+// tables (V x H per sample: L2-resident) and the row's (i, j), so that `pre` (2 KB per edge row: 2.1 GB at
+// max_vertices = 256) need not be written by the forward pass nor read here.
+struct PairSrc {
+    const float* Pa; const float* Pb; const float* wd; int wd_stride;
+    const int32_t* voff; const int32_t* eoff; const int32_t* esample;
+};
+
+template <int NS, int WPR, int KX = 0, bool PAIR = false>
 __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z,
                                                           int R, int D, const float* __restrict__ mu,
                                                           const float* __restrict__ rs, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, uint32_t seed,
                                                           uint32_t thresh, float scale, float* __restrict__ dz,
                                                           float* __restrict__ dz_sx8, float* __restrict__ part,
-                                                          const float* __restrict__ x0 = nullptr, int ldx = 0, int kx = 0) {
+                                                          const float* __restrict__ x0 = nullptr, int ldx = 0, int kx = 0,
+                                                          const PairSrc ps = PairSrc{}) {
     constexpr int RPI = 4 / WPR;                       // rows per workgroup iteration
     __shared__ float xsum[2][4][2];                    // [parity][wave][s1, s2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,9 +110,16 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     const bool has_ln = mu != nullptr;
     f32x4 gam[NS], bet[NS];
     f32x4 a_dg[NS], a_db[NS], a_dbias[NS];
+    f32x4 wdv[PAIR ? NS : 1];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = cbeg + lane * 4 + 256 * i;
+        if (PAIR) {
+            wdv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < cend)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wdv[i][k] = ps.wd[(size_t)(c + k) * ps.wd_stride];
+        }
         gam[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
         bet[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (gamma && c < cend) {
@@ -122,8 +139,20 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     // leaves a workgroup with nothing in flight between its rows
     f32x4 zn[NS], dn[NS];
     float mn = 0.f, rn = 1.f, xkn[KX > 0 ? KX : 1];
+    // PAIR: a workgroup takes a CONTIGUOUS block of edge rows, so that a wave steps from its row to its next one
+    // (RPI rows further) by counting j / i up — no lookups, and Pa[i] stays in registers while i does.  (With the
+    // grid-strided rows of the general form every row cost three dependent lookups before its two gathers could
+    // start: measured 0.8 ms slower than reading a stored pre at max_vertices = 256.)
+    auto row_of = [&](int it) { return PAIR ? (blockIdx.x * iters + it) * RPI + wrow : (it * gridDim.x + blockIdx.x) * RPI + wrow; };
+    int ps_s = 0, ps_vbase = 0, ps_v = 2, ps_eend = 0, ps_i = 0, ps_j = 1, pa_row = -1;
+    f32x4 pa[PAIR ? NS : 1];
+    if (PAIR) {
+        const int r0 = min(row_of(0), R - 1);
+        ps_s = ps.esample[r0]; ps_vbase = ps.voff[ps_s]; ps_v = ps.voff[ps_s + 1] - ps_vbase; ps_eend = ps.eoff[ps_s + 1];
+        edge_ij(r0 - ps.eoff[ps_s], ps_v, ps_i, ps_j);
+    }
     auto load_row = [&](int it) {
-        const int row = (it * gridDim.x + blockIdx.x) * RPI + wrow;
+        const int row = row_of(it);
         const bool live = it < iters && row < R;
         mn = (has_ln && live) ? mu[row] : 0.f;
         rn = (has_ln && live) ? rs[row] : 1.f;
@@ -131,19 +160,41 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
 #pragma unroll
             for (int k = 0; k < KX; ++k) xkn[k] = (live && k < kx) ? x0[(size_t)row * ldx + k] : 0.f;
         }
+        const int ri = ps_vbase + ps_i, rj = ps_vbase + ps_j;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int c = cbeg + lane * 4 + 256 * i;
             zn[i] = dn[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (live && c < cend) {
-                zn[i] = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
+                if (PAIR) {
+                    if (ri != pa_row) pa[i] = *reinterpret_cast<const f32x4*>(ps.Pa + (size_t)ri * D + c);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(ps.Pb + (size_t)rj * D + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) zn[i][k] = pa[i][k] + b[k] + xkn[0] * wdv[i][k];      // as pair_fwd_kernel formed it
+                } else {
+                    zn[i] = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
+                }
                 dn[i] = *reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c);
+            }
+        }
+        if (PAIR) {
+            pa_row = live ? ri : pa_row;
+            // step to this wave's next row: RPI edges further in the lexicographic (i, j) order, across samples
+            int e = row;
+#pragma unroll
+            for (int k = 0; k < RPI; ++k) {
+                ++e;
+                if (e >= R) break;
+                if (e == ps_eend) {                     // first edge of the next sample that has edges
+                    ps_s = ps.esample[e]; ps_vbase = ps.voff[ps_s]; ps_v = ps.voff[ps_s + 1] - ps_vbase; ps_eend = ps.eoff[ps_s + 1];
+                    ps_i = 0; ps_j = 1;
+                } else if (++ps_j == ps_v) { ++ps_i; ps_j = ps_i + 1; }
             }
         }
     };
     load_row(0);
     for (int it = 0; it < iters; ++it) {
-        const int row = (it * gridDim.x + blockIdx.x) * RPI + wrow;
+        const int row = row_of(it);
         const bool live = row < R;
         const float m = mn, r = rn;
         float xk[KX > 0 ? KX : 1];
@@ -594,6 +645,43 @@ extern "C" int wf3d_ln_act_bwd_wsum(const float* dh, const float* z, const float
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
+
+// The same pass for the first edge layer with its pre-activation rebuilt from the per-vertex tables (PairSrc above):
+// dh [Re, H] -> dz (may alias dh) + dgamma / dbeta + wsum, `pre` never read.  EdgePredictor.py:122-137 backward.
+extern "C" int wf3d_edge_pair_ln_bwd(const float* dh, const float* Pa, const float* Pb, const float* delta, const float* wdelta,
+                                     int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re,
+                                     int H, const float* mu, const float* rs, const float* gamma, const float* beta, int act,
+                                     float drop_p, uint32_t drop_seed, float* dz, float* dgamma, float* dbeta, float* wsum,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    WF3D_CHECK(Re > 0 && H > 0 && H % 4 == 0 && H <= 1024, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_ln_bwd: bad dims Re=%d H=%d", Re, H);
+    WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_edge_pair_ln_bwd: bad act/drop");
+    WF3D_CHECK(dh && Pa && Pb && delta && wdelta && voff && eoff && esample && mu && rs && gamma && beta && dz && dgamma && dbeta &&
+               wsum && dbeta == dgamma + H, WF3D_ERR_ARG, "wf3d_edge_pair_ln_bwd: null pointer, or dgamma / dbeta not one [2][H] buffer");
+    WF3D_CHECK(((uintptr_t)dh % 16 == 0) && ((uintptr_t)Pa % 16 == 0) && ((uintptr_t)Pb % 16 == 0) && ((uintptr_t)dz % 16 == 0) &&
+               ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_edge_pair_ln_bwd: pointers must be 16-byte aligned");
+    const int nblk = bwd_nblk(Re);
+    WF3D_CHECK(ws && ws_bytes >= (size_t)nblk * 4 * H * sizeof(float), WF3D_ERR_WS, "wf3d_edge_pair_ln_bwd: workspace too small");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float scale = 1.0f / (1.0f - drop_p);
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    const size_t lds = (size_t)4 * H * sizeof(float);
+    const PairSrc ps{Pa, Pb, wdelta, wdelta_stride, voff, eoff, esample};
+    const int wpr = H > 512 ? 4 : (H > 256 ? 2 : 1);
+#define WF3D_BWDP(NS_, WPR_)                                                                                                \
+    hipLaunchKernelGGL((ln_act_bwd_kernel<NS_, WPR_, 1, true>), dim3(nblk), dim3(256), lds, st, dh, nullptr, Re, H, mu, rs, gamma, \
+                       beta, act, drop_seed, thresh, scale, dz, nullptr, part, delta, 1, 1, ps)
+    if (wpr == 4) WF3D_BWDP(1, 4); else if (wpr == 2) WF3D_BWDP(1, 2); else WF3D_BWDP(1, 1);
+#undef WF3D_BWDP
+    WF3D_LAUNCH_CHECK();
+    launch_finalize(part, nblk, (size_t)4 * H, 2 * H, dgamma, st);
+    WF3D_LAUNCH_CHECK();
+    launch_finalize(part + 3 * H, nblk, (size_t)4 * H, H, wsum, st);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}
+
+extern "C" size_t wf3d_edge_pair_ln_bwd_ws_bytes(int Re, int H) { return wf3d_ln_act_bwd_wsum_ws_bytes(Re, H); }
 
 extern "C" int wf3d_rowdot_act_ok(int D) { return rowdot_ok(D) ? 1 : 0; }
 

@@ -112,6 +112,20 @@ __device__ __forceinline__ bool wf3d_keep(uint32_t seed, uint32_t row, uint32_t 
     return h >= thresh;
 }
 
+// edge rows of one sample: all pairs i < j of its v vertices in lexicographic order (EdgePredictor.py:83-86);
+// edge index e -> (i, j), and the index of pair (i, i + 1)
+__device__ __forceinline__ void edge_ij(int e, int v, int& i, int& j) {
+    const float b = (float)(2 * v - 1);
+    int ii = (int)floorf((b - sqrtf(fmaxf(b * b - 8.0f * (float)e, 0.f))) * 0.5f);
+    ii = max(0, min(ii, v - 2));
+    // offset(i) = i*(2v-i-1)/2 ; fix up float rounding
+    while (ii + 1 <= v - 2 && ((ii + 1) * (2 * v - ii - 2)) / 2 <= e) ++ii;
+    while (ii > 0 && (ii * (2 * v - ii - 1)) / 2 > e) --ii;
+    i = ii;
+    j = e - (ii * (2 * v - ii - 1)) / 2 + ii + 1;
+}
+__device__ __forceinline__ int edge_offset(int i, int v) { return (i * (2 * v - i - 1)) / 2; }
+
 __device__ __forceinline__ float wf3d_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -137,6 +137,10 @@ SIGNATURES = {
                               c_void_p]),
     "wf3d_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                               c_u32, c_void_p, c_void_p]),
+    "wf3d_edge_pair_ln_bwd_ws_bytes": (c_size_t, [c_int, c_int]),
+    "wf3d_edge_pair_ln_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_u32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_edge_pair_fwd_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                       ctypes.c_uint32, c_void_p, c_void_p]),

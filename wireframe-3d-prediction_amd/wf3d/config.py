@@ -38,3 +38,6 @@ SIDE_STREAM = os.environ.get("WF3D_SIDE_STREAM", "1") != "0"
 # on attention.in_proj_weight against 1.7e-4 with fp32 here — the 2e-4 bound on every gradient element is worth more.
 # WF3D_EDGE_X3=1 restores the x3 path (kept and tested: tests/test_kernels_gpu.py::test_gemm_x3_layouts).
 EDGE_X3 = os.environ.get("WF3D_EDGE_X3", "0") != "0"
+
+# Edge head: store the first edge layer's pre-activation even when backward could rebuild it (A/B switch, WF3D_KEEP_PRE=1).
+KEEP_PRE = os.environ.get("WF3D_KEEP_PRE", "0") != "0"

@@ -484,11 +484,18 @@ class EdgeFn(torch.autograd.Function):
         # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
         split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
         if split:
-            # the pair kernel holds each edge row in registers: it also emits gelu(LN(pre)) as the next GEMM's operand
-            pre, mu0, rs0, delta, h1 = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta, ln=(M1g, M1b, ACT_GELU, p1_, sd[2]))
+            # the pair kernel holds each edge row in registers: it also emits gelu(LN(pre)) as the next GEMM's operand.
+            # `pre` itself (2 KB per edge row) is stored only when something in backward reads it: with the wgrad of the
+            # second edge layer on the transposing-read kernel (operand h1) and the LayerNorm backward rebuilding the
+            # row from Pa / Pb (ops.edge_pair_ln_bwd), nothing does.
+            tn2 = (ops.gemm_split_tn_shape_ok(meta.Re, H // 2, H, H // 2, H)
+                   or ops.gemm_split_tn_shape_ok(meta.Re, H, H // 2, H, H // 2))          # what backward's _tn_either(dh2, h1) will say
+            keep_pre = not (tn2 and H <= 1024) or config.KEEP_PRE
+            pre, mu0, rs0, delta, h1 = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta, ln=(M1g, M1b, ACT_GELU, p1_, sd[2]), keep_pre=keep_pre)
         else:
             pre, mu0, rs0, delta = ops.edge_pair_fwd(Pa, Pb, cv, M0w, meta)
-        del Pa, Pb
+        if pre is not None:
+            Pa = Pb = None
         if split:
             (M4s, M4t), (M8s, M8t) = ops.split_weights([M4w, M8w])
             ctx.wT = (M4t, M8t)
@@ -508,7 +515,7 @@ class EdgeFn(torch.autograd.Function):
         _keep_params(ctx, params)
         ctx.cfg = (B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta)
         ctx.split, ctx.x3 = split, x3
-        ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2)
+        ctx.saved = (cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2, Pa, Pb)
         ctx.save_for_backward(probs)
         return probs
 
@@ -518,7 +525,7 @@ class EdgeFn(torch.autograd.Function):
         (P0w, P0b, P1g, P1b, P3w, P3b, P4g, P4b, Aw, Ab, Ow, Ob,
          M0w, M0b, M1g, M1b, M4w, M4b, M5g, M5b, M8w, M8b, M10w, M10b) = params
         B, V, H, heads, (pf_, pa_, p1_, p2_), sd, meta = ctx.cfg
-        cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2 = _saved(ctx)
+        cv, za, sa, zb, sb, f, qkv, cx, lse, Fm, pre, mu0, rs0, delta, z2, s2, z3, h1, h2, Pa, Pb = _saved(ctx)
         (probs,) = ctx.saved_tensors
         G = [None] * len(params)
         x3 = ctx.x3
@@ -578,7 +585,10 @@ class EdgeFn(torch.autograd.Function):
             G[16] = lv.run(lambda: ops.gemm(dz2, pre, TN, pro=p1, x3=x3), dz2, pre)
             dh1 = ops.gemm(dz2, M4w, NN, x3=x3)
         # LN/GELU backward of the first edge layer; the same pass yields the gradient of its distance-weight column
-        dpre, G[14], G[15], wsum = ops.ln_act_bwd_wsum(dh1, pre, delta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], inplace=True)
+        if pre is None:
+            dpre, G[14], G[15], wsum = ops.edge_pair_ln_bwd(dh1, Pa, Pb, delta, M0w, meta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2])
+        else:
+            dpre, G[14], G[15], wsum = ops.ln_act_bwd_wsum(dh1, pre, delta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], inplace=True)
         # split first layer backward
         dW0 = torch.empty_like(M0w)           # every column is written below: Wa | Wb | Wc | Wd | w_delta
         dW0[:, 2 * H + 6].copy_(wsum)

@@ -455,13 +455,14 @@ def _wdelta(W0, H):
     return col, 1
 
 
-def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None):
-    """ln = (gamma, beta, act, drop_p, seed): also return h = drop(act(LayerNorm(pre))) as an sx8 operand."""
+def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None, keep_pre=True):
+    """ln = (gamma, beta, act, drop_p, seed): also return h = drop(act(LayerNorm(pre))) as an sx8 operand.
+    keep_pre=False (with ln): the pre-activation is not stored (returned as None); edge_pair_ln_bwd rebuilds it."""
     _need_cuda(Pa, Pb, cv, W0)
     H = Pa.shape[1]
     wd, stride = _wdelta(W0, H)
     dev = Pa.device
-    pre = torch.empty(meta.Re, H, dtype=torch.float32, device=dev)
+    pre = torch.empty(meta.Re, H, dtype=torch.float32, device=dev) if (keep_pre or ln is None) else None
     mu = torch.empty(meta.Re, dtype=torch.float32, device=dev)
     rs = torch.empty(meta.Re, dtype=torch.float32, device=dev)
     delta = torch.empty(meta.Re, dtype=torch.float32, device=dev)
@@ -472,12 +473,31 @@ def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None):
         return pre, mu, rs, delta
     gamma, beta, act, drop_p, seed = ln
     _need_cuda(gamma, beta)
-    h = torch.empty_like(pre)
+    h = torch.empty(meta.Re, H, dtype=torch.float32, device=dev)
     check(_lib.load().wf3d_edge_pair_fwd_ln(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
                                             _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
                                             _p(gamma), _p(beta), act, float(drop_p), int(seed) & 0xFFFFFFFF, _p(h),
                                             _stream()), "edge_pair_fwd_ln")
     return pre, mu, rs, delta, h
+
+
+def edge_pair_ln_bwd(dh, Pa, Pb, delta, W0, meta, mu, rs, gamma, beta, act, drop_p=0.0, seed=0):
+    """LayerNorm / activation backward of the first edge layer whose pre-activation was not stored: rebuilt from Pa / Pb.
+    Returns (dpre (in place of dh), dgamma, dbeta, wsum) like ln_act_bwd_wsum(..., inplace=True)."""
+    _need_cuda(dh, Pa, Pb, delta, W0, mu, rs, gamma, beta)
+    if not (dh.is_contiguous() and Pa.is_contiguous() and Pb.is_contiguous() and delta.is_contiguous()):
+        raise RuntimeError("wf3d.edge_pair_ln_bwd: contiguous tensors required")
+    Re, H = dh.shape
+    wd, stride = _wdelta(W0, H)
+    duo = torch.empty(2, H, dtype=torch.float32, device=dh.device)
+    wsum = torch.empty(H, dtype=torch.float32, device=dh.device)
+    lib = _lib.load()
+    ws = scratch(lib.wf3d_edge_pair_ln_bwd_ws_bytes(Re, H), dh.device)
+    check(lib.wf3d_edge_pair_ln_bwd(_p(dh), _p(Pa), _p(Pb), _p(delta), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
+                                    _p(meta.esample), Re, H, _p(mu), _p(rs), _p(gamma), _p(beta), act, float(drop_p),
+                                    int(seed) & 0xFFFFFFFF, _p(dh), _p(duo[0]), _p(duo[1]), _p(wsum), _p(ws), ws.numel(),
+                                    _stream()), "edge_pair_ln_bwd")
+    return dh, duo[0], duo[1], wsum
 
 
 def edge_pair_bwd(dpre, delta, cv, W0, meta, coord=False):
