@@ -441,6 +441,9 @@ int wf3d_cloud_sample(const double* norm, const long* first, const int* cloud, c
 /* HOST function: the numbers of a whitespace-separated text file (.xyz: 8 per row; np.loadtxt, :98) into out[0..max_vals);
  * returns the count in the file (call again with a larger buffer if > max_vals), -1 unreadable, -2 not a number. */
 long wf3d_parse_floats(const char* path, double* out, long max_vals);
+/* Same (`#` comments skipped, C-locale numbers), and *ncols = values per row — np.loadtxt's second dimension;
+ * -3 if two non-empty rows hold different numbers of values. */
+long wf3d_parse_table(const char* path, double* out, long max_vals, long* ncols);
 
 /* ------------------------------------------------------------------------
  * Row f-4: evaluation post-processing behind the path, evaluate.py:74-110 and

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libwf3d_<tag>.so variants of one source with extra -D flags, for A/B timing in one process
-# tree on the GPU box:  scripts/build_variants.sh gemm_split.hip v1 "-DWF3D_DMA_SCHED=1" ...
+# tree on the GPU box:  scripts/build_variants.sh gemm_split.hip stamp "-DWF3D_STAMP=1" ...
 # Select with WF3D_LIB=wireframe-3d-prediction_amd/libwf3d_<tag>.so.
 set -e
 cd "$(dirname "$0")/../wireframe-3d-prediction_amd/csrc"

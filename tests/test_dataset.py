@@ -119,3 +119,24 @@ def test_device_cache_batches_equal_host_batches(augment):
     counts = torch.tensor([min(16, len(v)) for v in got["wf_vertices"]])
     out = model(got["point_clouds"], counts)
     assert torch.isfinite(out["vertices"]).all()
+
+
+def test_xyz_parser_takes_the_files_own_columns_comments_and_rejects_ragged_rows(tmp_path):
+    """np.loadtxt semantics of the C parser: the column count is the file's own (3-, 4-, 7-column .xyz files
+    load), `#` comments are skipped, rows of different lengths are an error rather than a silent reshape."""
+    from datasets.building3d import _read_xyz
+    p = tmp_path / "a.xyz"
+    p.write_text("# header line\n1.5 2 3\n4 5e0 6   # trailing comment\n\n-7 8 9.25\n")
+    got = _read_xyz(str(p))
+    assert got.shape == (3, 3) and np.array_equal(got, np.loadtxt(str(p), dtype=np.float64))
+    q = tmp_path / "b.xyz"
+    q.write_text("1 2 3 4 5 6 7\n8 9 10 11 12 13 14\n")
+    assert _read_xyz(str(q)).shape == (2, 7)
+    with pytest.raises(ValueError, match="expected 8"):
+        _read_xyz(str(q), ncols=8)
+    r = tmp_path / "c.xyz"
+    r.write_text("1 2 3 4\n5 6 7 8\n9 10 11 12\n13 14 15 16\n1 2 3 4 5 6 7 8\n")      # 24 values: a multiple of 8, but ragged
+    with pytest.raises(ValueError, match="different numbers of columns"):
+        _read_xyz(str(r))
+    with pytest.raises(OSError):
+        _read_xyz(str(tmp_path / "missing.xyz"))

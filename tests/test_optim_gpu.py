@@ -57,6 +57,45 @@ def test_clip_adam_matches_torch_over_several_steps(max_norm):
     assert int(ref2.state[pb[0]]["step"]) == 4
 
 
+def test_clip_adam_many_tensors_nan_norm_and_failed_step():
+    """(a) 170 tensors: the launch is cut into several tensor tables (<= 80 each) that must share ONE global norm;
+    (b) a NaN gradient poisons every gradient and parameter, as clip_grad_norm_ + Adam do;
+    (c) a step that is refused (an fp16 clip-only gradient) leaves every step counter where it was."""
+    from wf3d.optim import ClipAdam
+    shapes = [(37 + 3 * i,) if i % 3 else (5, 11 + i) for i in range(170)]
+    pa = [torch.nn.Parameter(t.clone()) for t in _make(3, shapes)]
+    pb = [torch.nn.Parameter(t.clone()) for t in _make(3, shapes)]
+    ref = torch.optim.Adam(pa, lr=1e-3, weight_decay=1e-6)
+    opt = ClipAdam(pb, lr=1e-3, weight_decay=1e-6, max_norm=1.0, norm_params=lambda: pb)
+    for step in range(2):
+        for p, q, g in zip(pa, pb, _make(20 + step, shapes)):
+            p.grad, q.grad = g.clone(), g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(pa, max_norm=1.0)
+        ref.step(); opt.step()
+        assert abs(float(opt.last_grad_norm) - float(n_ref)) <= 1e-5 * float(n_ref)
+        for p, q in zip(pa, pb):
+            assert H.elem_err(q.detach().cpu().numpy(), p.detach().cpu().numpy()) < 2e-6
+            assert H.elem_err(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 2e-6
+    # (c) refused step: nothing advances
+    bad = torch.nn.Parameter(torch.zeros(4, device=dev()))
+    bad.grad = torch.ones(4, device=dev(), dtype=torch.float16)
+    opt2 = ClipAdam(pb, lr=1e-3, max_norm=1.0, norm_params=lambda: pb + [bad])
+    opt2.load_state_dict(opt.state_dict())
+    with pytest.raises(RuntimeError, match="fp32 CUDA gradients"):
+        opt2.step()
+    assert all(int(opt2.state[q]["step"]) == 2 for q in pb)
+    # (b) NaN norm
+    for p, q, g in zip(pa, pb, _make(30, shapes)):
+        p.grad, q.grad = g.clone(), g.clone()
+    pa[5].grad[0] = float("nan"); pb[5].grad[0] = float("nan")
+    torch.nn.utils.clip_grad_norm_(pa, max_norm=1.0)
+    ref.step(); opt.step()
+    assert torch.isnan(opt.last_grad_norm)
+    for p, q in zip(pa, pb):
+        assert bool(torch.isnan(q.grad).all()) == bool(torch.isnan(p.grad).all()) is True
+        assert bool(torch.isnan(q).all()) == bool(torch.isnan(p).all()) is True
+
+
 def test_clip_adam_on_the_reference_trajectory():
     """tests/golden/traj.npz step 0 (reference model + reference loss + torch clip + torch Adam, generated from the imported
     reference): with ClipAdam in place of the two torch calls every tensor must move as far (update L1, 2e-3) and in the

@@ -11,6 +11,7 @@
 //                            augmentation parameters come from the host, drawn from numpy in the reference's order, so a
 //                            seeded run reproduces the reference's batches.
 // Plus the host-side text parser for .xyz files (np.loadtxt replacement): wf3d_parse_floats.
+#include <locale.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -106,31 +107,54 @@ extern "C" int wf3d_cloud_sample(const double* norm, const long* first, const in
     return WF3D_OK;
 }
 
-// Host: whitespace-separated decimal numbers of a text file into out[0..max_vals); returns how many the file holds
-// (> max_vals: call again with a larger buffer), -1 if the file cannot be read, -2 on a token that is not a number.
-extern "C" long wf3d_parse_floats(const char* path, double* out, long max_vals) {
+// Host: the numbers of a whitespace-separated text table.  `#` starts a comment (to the end of the line); numbers are
+// parsed in the C locale whatever the process locale is.  out[0..max_vals) receives the values in file order; returns
+// how many the file holds (> max_vals: call again with a larger buffer), -1 if the file cannot be read, -2 on a token
+// that is not a number, -3 (wf3d_parse_table only) if two non-empty rows hold different numbers of values.
+static long parse_numbers(const char* path, double* out, long max_vals, long* ncols) {
+    static locale_t c_loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
     FILE* f = fopen(path, "rb");
     if (!f) return -1;
-    fseek(f, 0, SEEK_END);
+    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return -1; }
     const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
+    if (sz < 0 || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return -1; }
     char* buf = (char*)malloc((size_t)sz + 1);
     if (!buf) { fclose(f); return -1; }
     const size_t got = fread(buf, 1, (size_t)sz, f);
     fclose(f);
+    if (got != (size_t)sz) { free(buf); return -1; }
     buf[got] = 0;
-    long n = 0;
+    long n = 0, in_row = 0, cols = 0;
+    bool ragged = false;
     char* p = buf;
+    auto end_row = [&]() {
+        if (in_row) {
+            if (cols == 0) cols = in_row; else if (in_row != cols) ragged = true;
+            in_row = 0;
+        }
+    };
     for (;;) {
-        while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') ++p;
+        while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
+        if (*p == '#') { while (*p && *p != '\n') ++p; }
+        if (*p == '\n') { end_row(); ++p; continue; }
         if (!*p) break;
         char* end;
-        const double v = strtod(p, &end);
+        const double v = c_loc ? strtod_l(p, &end, c_loc) : strtod(p, &end);
         if (end == p) { free(buf); return -2; }
         if (n < max_vals && out) out[n] = v;
-        ++n;
+        ++n; ++in_row;
         p = end;
     }
+    end_row();
     free(buf);
+    if (ncols) { *ncols = cols; if (ragged) return -3; }
     return n;
+}
+
+extern "C" long wf3d_parse_floats(const char* path, double* out, long max_vals) { return parse_numbers(path, out, max_vals, nullptr); }
+
+// Same, and *ncols = the number of values per row (np.loadtxt's second dimension).
+extern "C" long wf3d_parse_table(const char* path, double* out, long max_vals, long* ncols) {
+    if (!ncols) return -1;
+    return parse_numbers(path, out, max_vals, ncols);
 }

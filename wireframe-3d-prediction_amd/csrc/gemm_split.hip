@@ -24,20 +24,8 @@
 
 #include "wf3d_common.h"
 
-#ifndef WF3D_ABLATE
-#define WF3D_ABLATE 0      // timing-only builds: 1 = no DMA in the main loop, 2 = no LDS fragment reads, 4 = wgrad kernel with plain b128 fragment reads (wrong values)
-#endif
-
-#ifndef WF3D_NT_STORE
-#define WF3D_NT_STORE 0    // persistent kernel: 1 = non-temporal C stores (experiment)
-#endif
-
 #ifndef WF3D_STAMP
 #define WF3D_STAMP 0       // diagnostic build: the persistent kernel records s_memtime at every slice start (scripts/stamp_gemm.py)
-#endif
-
-#ifndef WF3D_DMA_SCHED
-#define WF3D_DMA_SCHED 0   // 256x256 kernel: 0 = DMA pieces spread over the slice, 1 = over its first half, 2 = bunched at the top
 #endif
 
 
@@ -120,7 +108,7 @@ __device__ __forceinline__ void mma12(f32x16 (&acc)[2][2], const Frag& f, bool a
                 constexpr int dummy = 0; (void)dummy;
                 const int piece = P0 + i * 2 + j;
                 __builtin_amdgcn_sched_barrier(0);
-                if (ahead && WF3D_ABLATE != 1) {
+                if (ahead) {
                     if (piece < 4) dma16(asrc[piece < 4 ? piece : 0] + kn, dA + piece * 8 * SBK);
                     else           dma16(bsrc[piece >= 4 ? piece - 4 : 0] + kn, dB + (piece - 4) * 8 * SBK);
                 }
@@ -201,9 +189,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split_dma3_kernel(const SplitPara
         const int kn = (kt + 2) * SBK;
         const float* As = smem + stage * T3_STAGE;
         const float* Bs = As + T3_A;
-        if (WF3D_ABLATE != 2 || kt == kt0) load_frag(X, As, Bs, wm, wn, l31, h, fsw, 0);
+        load_frag(X, As, Bs, wm, wn, l31, h, fsw, 0);
         mma12<0>(acc, X, ahead, asrc, bsrc, kn, dA, dB);
-        if (WF3D_ABLATE != 2 || kt == kt0) load_frag(Y, As, Bs, wm, wn, l31, h, fsw, 1);
+        load_frag(Y, As, Bs, wm, wn, l31, h, fsw, 1);
         mma12<3>(acc, Y, ahead, asrc, bsrc, kn, dA, dB);
         // retire slice kt+1 (all but the 6 youngest DMA pieces), make sure this wave's LDS reads
         // of slice kt are done (lgkmcnt) before anyone may overwrite the stage, then publish.
@@ -537,11 +525,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
     asm volatile("" ::: "memory");
 
     auto rdA = [&](const float* As, int i, bool lo) -> f32x4 {
-        if (TN && WF3D_ABLATE != 4) return tr_frag16(reinterpret_cast<const char*>(As), lo ? (a_tn[i] ^ 16) : a_tn[i]);
+        if (TN) return tr_frag16(reinterpret_cast<const char*>(As), lo ? (a_tn[i] ^ 16) : a_tn[i]);
         return *reinterpret_cast<const f32x4*>(As + a_row + i * 16 * SBK + (lo ? c_lo : c_hi));
     };
     auto rdB = [&](const float* Bs, int j, bool lo) -> f32x4 {
-        if (TN && WF3D_ABLATE != 4) return tr_frag16(reinterpret_cast<const char*>(Bs), lo ? (b_tn[j] ^ 16) : b_tn[j]);
+        if (TN) return tr_frag16(reinterpret_cast<const char*>(Bs), lo ? (b_tn[j] ^ 16) : b_tn[j]);
         return *reinterpret_cast<const f32x4*>(Bs + b_row + j * 16 * SBK + (lo ? c_lo : c_hi));
     };
     // Same software pipeline across the barrier as the persistent kernel (x16p_slice): the wait + barrier that publish
@@ -571,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             pah[(i + 1) & 1] = rdA(As, i + 1, false);
             pal[(i + 1) & 1] = rdA(As, i + 1, true);
             __builtin_amdgcn_sched_barrier(0);
-            if (i < 4 && WF3D_ABLATE != 1) {          // B(kt+1) first, A(kt+2) last: the wait below skips exactly the 4 youngest
+            if (i < 4) {          // B(kt+1) first, A(kt+2) last: the wait below skips exactly the 4 youngest
                 if (i < 2) { dma16_asm(bsrc[2 * i] + kb, dB + (2 * i) * 8 * SBK);         dma16_asm(bsrc[2 * i + 1] + kb, dB + (2 * i + 1) * 8 * SBK); }
                 else       { dma16_asm(asrc[2 * i - 4] + ka, dA + (2 * i - 4) * 8 * SBK); dma16_asm(asrc[2 * i - 3] + ka, dA + (2 * i - 3) * 8 * SBK); }
             }
@@ -647,7 +635,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_x16_kernel(const SplitParam
             f32x4 v = acc[i][j];
             float* c = split ? p.slab + ((size_t)zi * p.M + row) * p.N + col : p.C + (size_t)row * p.ldc + col;
             if (!split) v += bv[j];
-            if (WF3D_ABLATE == 3 && v[0] != 1234.5f) continue;       // timing-only: no C stores
             if (vec && col + 3 < p.N) {
                 if (!split && p.accumulate) v += *reinterpret_cast<const f32x4*>(c);
                 *reinterpret_cast<f32x4*>(c) = v;
@@ -1010,19 +997,21 @@ void launch_split_reduce(const SplitParams& p, hipStream_t st) {
 // forward / dgrad GEMMs), else 3 (few tiles, long split-K reductions).  Measured on the encoder
 // shapes, same process: 6 is 11-14 % faster than 4; 5 equals 4 with its DMA issued early (+5 %).
 int cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
+    // per device (a process may drive several); WF3D_RESERVED_CUS=r: the persistent kernel launches on r CUs fewer
+    // (rounded to whole XCD-octets).  Since its tiles are claimed, not dealt, a CU held by another stream's kernel no
+    // longer costs a round — the switch remains for experiments.
+    static std::atomic<int> cache[16];
+    static const int reserved = [] { const char* e = getenv("WF3D_RESERVED_CUS"); return e ? atoi(e) : 0; }();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const bool cached = dev >= 0 && dev < 16;
+    int v = cached ? cache[dev].load(std::memory_order_relaxed) : 0;
+    if (v == 0) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        // WF3D_RESERVED_CUS=r: the persistent kernel leaves r CUs (rounded to whole XCD-octets) to whatever else runs on the
-        // chip.  Its workgroups need a whole CU's LDS, so ONE CU held by another stream's kernel (a collective) leaves one of
-        // 256 workgroups waiting for a full round: +45-60 % on the launch (scripts/bench_contention.py).
-        const char* e = getenv("WF3D_RESERVED_CUS");
-        const int r = e ? atoi(e) : 0;
-        if (r > 0 && v - r >= 8) v = (v - r) / 8 * 8;
-        return v;
-    }();
-    return n;
+        if (reserved > 0 && v - reserved >= 8) v = (v - reserved) / 8 * 8;
+        if (cached) cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 // 6 = 256x256 tile on v_mfma_f32_16x16x32_bf16 (gemm_split_x16_kernel / its persistent form): >= 192 tiles (3/4 of the CUs) and N a

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const AdamArgs a, const 
     for (int i = threadIdx.x; i < npart; i += 256) s += partials[i];
     const float norm = sqrtf(block_sum(s, s_red));
     float coef = max_norm / (norm + 1e-6f);                      // clip_grad_norm_: clamp(max_norm / (total_norm + 1e-6), max=1)
-    coef = max_norm > 0.f ? fminf(coef, 1.0f) : 1.0f;            // max_norm <= 0: no clipping
+    // max_norm <= 0: no clipping.  A NaN norm must poison every gradient as clip_grad_norm_ does (torch.clamp keeps the
+    // NaN): fminf(NaN, 1) would return 1 and let a step with a non-finite gradient through unscaled.
+    coef = max_norm > 0.f ? (norm != norm ? norm : fminf(coef, 1.0f)) : 1.0f;
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
     const int t = find_tensor(a, blockIdx.x);
     const long base = (long)(blockIdx.x - a.blk_begin[t]) * OPT_CHUNK;

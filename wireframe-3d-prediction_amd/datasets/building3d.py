@@ -12,6 +12,7 @@ coordinates are UTM metres — fp32 cannot hold them), normalised once on the de
 writes the model's `[B, num_points, C]` fp32 input directly — no per-sample file I/O, no per-sample host arrays."""
 import ctypes
 import glob
+import operator
 import os
 from collections import defaultdict
 
@@ -20,22 +21,34 @@ import torch
 from torch.utils.data import Dataset
 
 
-def _read_xyz(path, ncols=8):
-    """[n, ncols] float64 rows of a whitespace-separated text file (what `np.loadtxt(path, dtype=np.float64)` returns,
-    reference :98), through wf3d_parse_floats."""
-    from wf3d import _lib
-    lib = _lib.load()
+def _read_xyz(path, ncols=None):
+    """[n, c] float64 rows of a whitespace-separated text file — what `np.loadtxt(path, dtype=np.float64)` returns
+    (reference :98): the column count is the file's own (every row must have it; `ncols`, if given, is checked against
+    it), `#` starts a comment.  Parsed by the library's C routine (wf3d_parse_table, ~30x faster than loadtxt); if
+    libwf3d.so cannot be loaded at all — a host without ROCm preparing data — np.loadtxt does the same job."""
+    try:
+        from wf3d import _lib
+        lib = _lib.load()
+    except (OSError, ImportError):
+        arr = np.atleast_2d(np.loadtxt(path, dtype=np.float64))
+        if ncols is not None and arr.shape[1] != ncols:
+            raise ValueError(f"{path}: {arr.shape[1]} columns, expected {ncols}")
+        return arr
     cap = max(1024, os.path.getsize(path) // 4)
+    cols = ctypes.c_long(0)
     buf = np.empty(cap, dtype=np.float64)
-    n = lib.wf3d_parse_floats(path.encode(), buf.ctypes.data_as(ctypes.c_void_p), cap)
+    n = lib.wf3d_parse_table(path.encode(), buf.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(cols))
     if n > cap:
         buf = np.empty(n, dtype=np.float64)
-        n = lib.wf3d_parse_floats(path.encode(), buf.ctypes.data_as(ctypes.c_void_p), n)
+        n = lib.wf3d_parse_table(path.encode(), buf.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(cols))
+    if n == -3:
+        raise ValueError(f"{path}: rows with different numbers of columns")
     if n < 0:
         raise OSError(f"cannot parse {path} (code {n})")
-    if n % ncols:
-        raise ValueError(f"{path}: {n} numbers is not a multiple of {ncols} columns")
-    return buf[:n].reshape(-1, ncols).copy()
+    c = int(cols.value)
+    if ncols is not None and c != ncols and n:
+        raise ValueError(f"{path}: {c} columns, expected {ncols}")
+    return buf[:n].reshape(-1, c).copy() if n else np.empty((0, ncols or 0))
 
 
 def load_wireframe(wireframe_file):
@@ -54,20 +67,18 @@ def load_wireframe(wireframe_file):
 
 
 def save_wireframe(vertices, edges, wireframe_file):
-    """Inverse of load_wireframe (reference :34-47)."""
+    """Write an .obj that load_wireframe reads back: one `v x y z` line per vertex, one 1-based `l i j` line per edge."""
+    lines = ["v " + " ".join(str(c) for c in v) for v in np.asarray(vertices)]
+    lines += ["l " + " ".join(str(int(k) + 1) for k in e) for e in np.asarray(edges)]
     with open(wireframe_file, "w") as f:
-        for v in vertices:
-            f.write("v " + " ".join(map(str, v)) + "\n")
-        for e in edges:
-            f.write("l " + " ".join(map(str, e + 1)) + "\n")
+        f.write("\n".join(lines) + "\n")
 
 
-def random_sampling(pc, num_points, replace=None, return_choices=False):
-    """`num_points` random rows, with replacement iff the cloud is smaller (reference :50-65)."""
+def random_sampling(pc, num_points, replace=None):
+    """`num_points` random rows, with replacement iff the cloud is smaller (one np.random.choice draw, as reference :50-65)."""
     if replace is None:
         replace = pc.shape[0] < num_points
-    choices = np.random.choice(pc.shape[0], num_points, replace=replace)
-    return (pc[choices], choices) if return_choices else pc[choices]
+    return pc[np.random.choice(pc.shape[0], num_points, replace=replace)]
 
 
 def rotz(t):
@@ -188,10 +199,6 @@ class Building3DReconstructionDataset(Dataset):
         wf_files = [p.replace(os.path.sep + "xyz", os.path.sep + "wireframe").replace(".xyz", ".obj") for p in pc_files]
         return pc_files, wf_files
 
-    def print_self_values(self):
-        for attribute, value in vars(self).items():
-            print(attribute, "=", value)
-
 
 class DeviceCloudCache:
     """All clouds of a dataset resident in HBM, normalised once; batches are produced by one kernel.
@@ -227,7 +234,14 @@ class DeviceCloudCache:
     def batch(self, indices):
         from wf3d import _lib
         from wf3d.ops import _stream
-        ds, P, B = self.ds, self.ds.num_points, len(indices)
+        ds, P = self.ds, self.ds.num_points
+        # the kernel indexes device arrays with these: normalise Python's negative indices and refuse anything out of
+        # range here (the host arrays would wrap around silently, the device read would not)
+        indices = [operator.index(i) for i in indices]
+        indices = [i + len(self.n) if i < 0 else i for i in indices]
+        if any(not 0 <= i < len(self.n) for i in indices):
+            raise IndexError(f"DeviceCloudCache.batch: index out of range for {len(self.n)} clouds")
+        B = len(indices)
         choice = np.empty((B, P), dtype=np.int32)
         aug = np.empty((B, 4), dtype=np.float64)
         items = []

@@ -49,13 +49,28 @@ class ClipAdam(torch.optim.Optimizer):
             extra = [p for p in src if id(p) not in own_ids and p.grad is not None]
         if not own and not extra:
             return loss
+        # validate everything and collect the pointers FIRST; the per-parameter step counters are advanced only after the
+        # launch has been accepted, so that a failed step leaves the optimizer where it was and can simply be retried
         steps = set()
         P, G, M, V, N = [], [], [], [], []
         keep = []
         for p in own:
             g = p.grad
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32):
-                raise RuntimeError("ClipAdam: contiguous fp32 CUDA parameters only")
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_cuda and g.dtype == torch.float32):
+                raise RuntimeError("ClipAdam: contiguous fp32 CUDA parameters (and fp32 CUDA gradients) only")
+            st = self.state[p]
+            steps.add(int(st["step"]) + 1 if st else 1)
+        for p in extra:
+            g = p.grad
+            if not (g.is_cuda and g.dtype == torch.float32):
+                raise RuntimeError("ClipAdam: the clip-only tensors of norm_params need fp32 CUDA gradients "
+                                   f"(got {g.dtype} on {g.device})")
+        if len(steps) > 1:
+            raise RuntimeError("ClipAdam: parameters are at different Adam steps (a parameter without gradient in an earlier step); "
+                               "use torch.optim.Adam for such models")
+        step = steps.pop() if steps else 1
+        for p in own:
+            g = p.grad
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
             st = self.state[p]
@@ -63,8 +78,6 @@ class ClipAdam(torch.optim.Optimizer):
                 st["step"] = torch.tensor(0.0)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] += 1
-            steps.add(int(st["step"]))
             P.append(p.data_ptr()); G.append(g.data_ptr()); M.append(st["exp_avg"].data_ptr()); V.append(st["exp_avg_sq"].data_ptr())
             N.append(p.numel())
         for p in extra:                                   # clip-only tensors (in the norm, scaled, never updated)
@@ -73,10 +86,6 @@ class ClipAdam(torch.optim.Optimizer):
                 g = p.grad = g.contiguous()
             P.append(None); G.append(g.data_ptr()); M.append(None); V.append(None); N.append(g.numel())
             keep.append(g)
-        if len(steps) > 1:
-            raise RuntimeError("ClipAdam: parameters are at different Adam steps (a parameter without gradient in an earlier step); "
-                               "use torch.optim.Adam for such models")
-        step = steps.pop() if steps else 1
         n = len(G)
         vp = ctypes.c_void_p * n
         numel = (ctypes.c_long * n)(*N)
@@ -89,6 +98,8 @@ class ClipAdam(torch.optim.Optimizer):
         check(lib.wf3d_clip_adam_step(vp(*P), vp(*G), vp(*M), vp(*V), numel, n, float(self.max_norm or 0.0), float(group["lr"]),
                                       float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                                       ws.data_ptr(), nws, norm.data_ptr(), _stream()), "clip_adam_step")
+        for p in own:
+            self.state[p]["step"] += 1
         # the kernel wrote parameters, gradients and moments through raw pointers: tell autograd's version counters
         # (a graph that still holds the old values must fail loudly, as it does after torch.optim.Adam.step())
         bump = torch.autograd.graph.increment_version
