@@ -60,7 +60,7 @@ def test_clip_adam_matches_torch_over_several_steps(max_norm):
 def test_clip_adam_many_tensors_nan_norm_and_failed_step():
     """(a) 170 tensors: the launch is cut into several tensor tables (<= 80 each) that must share ONE global norm;
     (b) a NaN gradient poisons every gradient and parameter, as clip_grad_norm_ + Adam do;
-    (c) a step that is refused (an fp16 clip-only gradient) leaves every step counter where it was."""
+    (c) a step that is refused (a clip-only gradient on the CPU) leaves every step counter where it was."""
     from wf3d.optim import ClipAdam
     shapes = [(37 + 3 * i,) if i % 3 else (5, 11 + i) for i in range(170)]
     pa = [torch.nn.Parameter(t.clone()) for t in _make(3, shapes)]
@@ -77,8 +77,8 @@ def test_clip_adam_many_tensors_nan_norm_and_failed_step():
             assert H.elem_err(q.detach().cpu().numpy(), p.detach().cpu().numpy()) < 2e-6
             assert H.elem_err(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 2e-6
     # (c) refused step: nothing advances
-    bad = torch.nn.Parameter(torch.zeros(4, device=dev()))
-    bad.grad = torch.ones(4, device=dev(), dtype=torch.float16)
+    bad = torch.nn.Parameter(torch.zeros(4))                       # a clip-only tensor whose gradient lives on the CPU
+    bad.grad = torch.ones(4)
     opt2 = ClipAdam(pb, lr=1e-3, max_norm=1.0, norm_params=lambda: pb + [bad])
     opt2.load_state_dict(opt.state_dict())
     with pytest.raises(RuntimeError, match="fp32 CUDA gradients"):
