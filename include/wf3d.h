@@ -426,6 +426,18 @@ int wf3d_clip_adam_step(float* const* params, float* const* grads, float* const*
                         const long* numel, int ntensors, double max_norm, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int step, float* ws, size_t ws_floats, float* total_norm, void* stream);
 
+/* Training-step meter (reference train.py:145-157: total_loss.item() twice and a host copy of sample 0's vertices on EVERY
+ * step, for the loss history, the best loss and a monitoring RMSE).  One small launch per step folds them into a
+ * device-resident record; the loop copies it back only when it logs.
+ *   state[0] = steps recorded, [1] = best total loss, [2] = best vertex RMSE, [3..7] = last total / vertex / existence /
+ *   edge loss and RMSE, [8 .. 8 + capacity) = ring of the last `capacity` total losses (step t at 8 + t % capacity);
+ *   the caller zeroes state[0] once.  RMSE = sqrt(mean((pred - target)^2)) over the first count0[0] (<= max_v) vertices
+ *   x 3 coordinates of sample 0; pred_stride / target_stride = floats between consecutive vertices.
+ *   vertex_loss / existence_loss / edge_loss / count0 may be NULL (recorded as 0 / count = max_v). */
+int wf3d_meter_update(const float* total, const float* vertex_loss, const float* existence_loss, const float* edge_loss,
+                      const float* pred_vertices, long pred_stride, const float* target_vertices, long target_stride,
+                      const int64_t* count0, int max_v, float* state, int capacity, void* stream);
+
 /* ------------------------------------------------------------------------
  * Row f-3: the input pipeline, datasets/building3d.py:95-158.  Clouds are parsed once, normalised once on
  * the device in float64 (the raw coordinates are UTM metres: colour / 256 for columns [color_lo, color_hi), centroid and

@@ -112,3 +112,32 @@ def test_device_loss_drives_the_model_backward():
     ref, _ = loss_cpu.wireframe_loss(preds_cpu, {k: v.cpu() for k, v in tg.items()}, 3.0, 1.5, 1.0)
     assert abs(float(ld["total_loss"]) - float(ref["total_loss"])) < 1e-5 * float(ref["total_loss"])
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "spatial_proj" not in n)
+
+
+@pytest.mark.gpu
+def test_train_meter_tracks_the_reference_loop_quantities_without_syncs():
+    """wf3d.meter.TrainMeter against train.py:145-157 evaluated on the host: loss history, best loss, the monitoring RMSE of
+    sample 0 over its first counts[0] vertices and its running minimum, the last loss terms — read back in one copy."""
+    import numpy as np
+    from wf3d.meter import TrainMeter
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, V = 3, 9
+    counts = torch.tensor([7, 2, 9])
+    meter = TrainMeter(dev, history=4)
+    target = torch.randn(B, V, 3, generator=g)
+    hist, best_loss, best_rmse = [], float("inf"), float("inf")
+    for step in range(7):
+        out4 = torch.randn(B, V, 4, generator=g).to(dev)                # `vertices` is a strided view of [B, V, 4] in the model
+        losses = {k: torch.rand((), generator=g).to(dev) * (3 - 0.3 * step) for k in ("total_loss", "vertex_loss", "existence_loss", "edge_loss")}
+        meter.update(losses, out4[:, :, :3], target.to(dev), counts.to(dev))
+        pv = out4[0, :7, :3].cpu().numpy()
+        rmse = float(np.sqrt(np.mean((pv - target[0, :7].numpy()) ** 2)))
+        hist.append(float(losses["total_loss"]))
+        best_loss, best_rmse = min(best_loss, hist[-1]), min(best_rmse, rmse)
+    m = meter.read()
+    assert m["steps"] == 7
+    assert abs(m["best_loss"] - best_loss) < 1e-6 and abs(m["best_vertex_rmse"] - best_rmse) < 1e-6
+    assert abs(m["vertex_rmse"] - rmse) < 1e-6 and abs(m["total_loss"] - hist[-1]) < 1e-7
+    assert abs(m["edge_loss"] - float(losses["edge_loss"])) < 1e-7
+    assert np.allclose(m["loss_history"], hist[-4:], atol=1e-7)          # ring of the last `history` steps, oldest first

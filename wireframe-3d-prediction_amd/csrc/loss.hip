@@ -422,3 +422,52 @@ extern "C" int wf3d_loss_assign_counts(const float* cost, const int64_t* counts,
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Training-step meter (train.py:145-157): the reference reads total_loss.item() twice and copies sample 0's vertices to
+// the host EVERY step to track loss history, best loss and a monitoring RMSE.  Here one small launch per step folds
+// those into a device-resident record that the loop reads back whenever it logs (one copy per k steps, no per-step sync).
+//   state[0] = steps recorded, [1] = best total loss, [2] = best vertex RMSE, [3..7] = last total / vertex / existence /
+//   edge loss and RMSE, [8 .. 8 + capacity) = ring of the last `capacity` total losses (step t at 8 + t % capacity).
+//   RMSE = sqrt(mean((pred - target)^2)) over the first counts[0] vertices x 3 coordinates of sample 0 (train.py:148-150).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void meter_update_kernel(const float* __restrict__ total, const float* __restrict__ lv,
+                                                            const float* __restrict__ le, const float* __restrict__ ld,
+                                                            const float* __restrict__ pred, long pstride,
+                                                            const float* __restrict__ tgt, long tstride,
+                                                            const int64_t* __restrict__ count0, int max_v,
+                                                            float* __restrict__ state, int capacity) {
+    __shared__ float red[4];
+    long c = count0 ? count0[0] : (long)max_v;
+    c = c < 0 ? 0 : (c > max_v ? max_v : c);
+    float s = 0.f;
+    for (long i = threadIdx.x; i < c * 3; i += 256) {
+        const float d = pred[(i / 3) * pstride + i % 3] - tgt[(i / 3) * tstride + i % 3];
+        s += d * d;
+    }
+    s = wf3d_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sq = (red[0] + red[1]) + (red[2] + red[3]);
+        const float rmse = c > 0 ? sqrtf(sq / (float)(c * 3)) : 0.f;
+        const float t = total[0];
+        const long step = (long)state[0];
+        state[1] = step == 0 ? t : fminf(state[1], t);
+        state[2] = step == 0 ? rmse : fminf(state[2], rmse);
+        state[3] = t; state[4] = lv ? lv[0] : 0.f; state[5] = le ? le[0] : 0.f; state[6] = ld ? ld[0] : 0.f; state[7] = rmse;
+        if (capacity > 0) state[8 + step % capacity] = t;
+        state[0] = (float)(step + 1);
+    }
+}
+
+extern "C" int wf3d_meter_update(const float* total, const float* vertex_loss, const float* existence_loss, const float* edge_loss,
+                                 const float* pred_vertices, long pred_stride, const float* target_vertices, long target_stride,
+                                 const int64_t* count0, int max_v, float* state, int capacity, void* stream) {
+    WF3D_CHECK(max_v >= 0 && capacity >= 0, WF3D_ERR_ARG, "wf3d_meter_update: bad dims");
+    WF3D_CHECK(total && state && (max_v == 0 || (pred_vertices && target_vertices)), WF3D_ERR_ARG, "wf3d_meter_update: null pointer");
+    hipLaunchKernelGGL(meter_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, total, vertex_loss, existence_loss, edge_loss,
+                       pred_vertices, pred_stride, target_vertices, target_stride, count0, max_v, state, capacity);
+    WF3D_LAUNCH_CHECK();
+    return WF3D_OK;
+}

@@ -172,6 +172,8 @@ SIGNATURES = {
                                     c_size_t, c_void_p, c_void_p]),
     "wf3d_cloud_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf3d_cloud_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_meter_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p,
+                                  c_int, c_void_p, c_int, c_void_p]),
     "wf3d_parse_floats": (ctypes.c_long, [ctypes.c_char_p, c_void_p, ctypes.c_long]),
     "wf3d_parse_table": (ctypes.c_long, [ctypes.c_char_p, c_void_p, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]),
     "wf3d_edge_endpoints": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
