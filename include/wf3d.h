@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WF3D_VERSION 104 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended); 103: wf3d_set_option; 104: wf3d_edge_pair_ln_bwd, wf3d_edge_pair_fwd_ln accepts pre = NULL */
+#define WF3D_VERSION 105 /* 101: wf3d_gemm_t gained `x3`; 102: `lr_u`, `lr_v`, `lr_k`, `ld_lr_u`, `ld_lr_v` (all appended); 103: wf3d_set_option; 104: wf3d_edge_pair_ln_bwd, wf3d_edge_pair_fwd_ln accepts pre = NULL; 105: `vd` (coordinates per vertex, 1..8) in the edge-head entry points, wf3d_meter_update, wf3d_parse_table */
 
 #define WF3D_OK 0
 #define WF3D_ERR_ARG (-1)
@@ -324,11 +324,13 @@ int wf3d_vertex_finalize_bwd(const float* exist, const float* dexist, const floa
  * counts[s] predicted vertices) and edge rows eoff[s]..eoff[s+1]-1 (all pairs
  * i<j in lexicographic order); vsample/esample map a row back to its sample.
  * ------------------------------------------------------------------------ */
-/* cv[r,0:3] = verts[s, r-voff[s], 0:3]; strides in floats (vertices is a view of [B,V,4]) */
+/* vd = coordinates per vertex, EdgePredictor(vertex_dim=...), 1..8 (the model uses 3: EdgePredictor.py:19,
+ * PointCloudToWireframe.py:38).
+ * cv[r,0:vd] = verts[s, r-voff[s], 0:vd]; strides in floats (vertices is a view of [B,V,4]) */
 int wf3d_edge_gather_verts(const float* verts, long sample_stride, long vertex_stride, const int32_t* voff,
-                           const int32_t* vsample, int Rv, float* cv, void* stream);
-/* dverts[B,V,3] = scatter of dcv rows, zero for v >= counts[s] */
-int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V, float* dverts, void* stream);
+                           const int32_t* vsample, int Rv, int vd, float* cv, void* stream);
+/* dverts[B,V,vd] = scatter of dcv rows, zero for v >= counts[s] */
+int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V, int vd, float* dverts, void* stream);
 
 /* 8-head self-attention of nn.MultiheadAttention (EdgePredictor.py:41-46,109):
  * qkv[Rv, 3E] packed in_proj output; one workgroup per (head, sample); writes
@@ -342,17 +344,17 @@ int wf3d_attn_bwd(const float* qkv, const float* dctx, const float* ctx, const f
 
 /* Split first layer of edge_mlp (EdgePredictor.py:122-137):
  * pre[e,:] = Pa[i,:] + Pb[j,:] + |c_i - c_j| * wdelta  for edge e = (i, j), plus
- * the row's LayerNorm statistics and delta[e] = |c_i - c_j|.  wdelta is column
- * 2H+6 of edge_mlp.0.weight, read with stride wdelta_stride (= 2H+7). */
+ * the row's LayerNorm statistics and delta[e] = |c_i - c_j| over the vd coordinates of cv [Rv, vd].  wdelta is column
+ * 2H+2vd of edge_mlp.0.weight, read with stride wdelta_stride (= 2H+2vd+1, or 1 for a gathered copy). */
 int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
-                       const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
+                       const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, int vd, float eps,
                        float* pre, float* mu, float* rs, float* delta, void* stream);
 /* Same, and also h = drop(act(LayerNorm(pre))) as the sx8 operand of the next Linear (edge_mlp[1..4] of
  * EdgePredictor.py:57-60) from the row the wave still holds: saves wf3d_ln_prep's second read of pre.
  * pre may be NULL: the pre-activation is then not stored at all (2 KB per edge row at hidden 512) and the backward
  * rebuilds it from Pa / Pb with wf3d_edge_pair_ln_bwd below. */
 int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
-                          const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
+                          const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, int vd, float eps,
                           float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
                           float drop_p, uint32_t drop_seed, void* h_sx8, void* stream);
 /* LayerNorm / activation backward of that first edge layer with its pre-activation REBUILT, not read:
@@ -368,11 +370,11 @@ int wf3d_edge_pair_ln_bwd(const float* dh, const float* Pa, const float* Pb, con
                           void* stream);
 /* dPa[v] / dPb[v] = segmented sums of dpre over the edges where v is i / j, and
  * dcv[v] = sum over incident edges of (dpre[e]·wdelta)(c_v - c_other)/delta[e]
- *          (+ dPa[v]·Wc + dPb[v]·Wd when wcoord != NULL: wcoord[c * wcoord_stride + 0..5] = [Wc[c, :] | Wd[c, :]], the
- *          coordinate columns 2H..2H+5 of edge_mlp[0].weight, EdgePredictor.py:130-137). */
+ *          (+ dPa[v]·Wc + dPb[v]·Wd when wcoord != NULL: wcoord[c * wcoord_stride + 0..2vd) = [Wc[c, :] | Wd[c, :]], the
+ *          coordinate columns 2H..2H+2vd-1 of edge_mlp[0].weight, EdgePredictor.py:130-137).  dcv is [Rv, vd]. */
 int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,
                        int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample, int Rv,
-                       int H, float* dPa, float* dPb, float* dcv, const float* wcoord, int wcoord_stride, void* stream);
+                       int H, int vd, float* dPa, float* dPb, float* dcv, const float* wcoord, int wcoord_stride, void* stream);
 
 /* probs[s, j] = sigmoid(logit[eoff[s] + j]) for j < E_s and exactly 0.0 for the padding j >= E_s: the whole padded
  * [B, max_e] output of PointCloudToWireframe.py:103-112 in one pass (no zero-fill first), and its backward. */

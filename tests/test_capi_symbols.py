@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"libwf3d.so does not export {n}"
         assert n in _lib.SIGNATURES, f"wf3d/_lib.py has no ctypes signature for {n}"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.wf3d_version() == 104  # (parse_table added without a bump: host-side helper)
+    assert lib.wf3d_version() == 105
 
 
 def test_library_exports_nothing_but_the_header():

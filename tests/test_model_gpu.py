@@ -85,6 +85,52 @@ def test_small_edge_vs_golden(V, precision):
             assert p.grad is None, n            # spatial_proj is never used
 
 
+@pytest.mark.parametrize("vd", [2, 4, 6])
+def test_edge_head_other_vertex_dims_vs_oracle(vd, precision):
+    """EdgePredictor(vertex_dim != 3) (reference models/EdgePredictor.py:19-31 is general in it; PointCloudToWireframe
+    uses 3): forward and every gradient against the fp64 oracle on a ragged pair of samples.  vd <= 4 takes the
+    coordinate columns as a low-rank GEMM epilogue, vd = 6 as a separate accumulate."""
+    from models.EdgePredictor import EdgePredictor
+    torch.manual_seed(40 + vd)
+    ep = EdgePredictor(vd, 64, 2).to(dev())
+    for sub in ep.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+    ep.attention.dropout = 0.0
+    ep.train()
+    with torch.no_grad():
+        for n, p_ in ep.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.05 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
+    g = torch.Generator().manual_seed(7)
+    counts = [7, 4]
+    v = torch.randn(2, 7, vd, generator=g)
+    vg = v.clone().to(dev()).requires_grad_()
+    probs = ep.forward_ragged(vg, counts)
+    cot = torch.randn(probs.shape, generator=g)
+    (probs * cot.to(dev())).sum().backward()
+    P = {"edge_predictor." + n: p_.detach().cpu().double().requires_grad_() for n, p_ in ep.named_parameters()}
+    vr = v.double().requires_grad_()
+    tot = 0.0
+    for s_, c in enumerate(counts):
+        pr, _ = oracle.edge_forward(P, vr[s_:s_ + 1, :c], num_heads=2)
+        assert H.elem_err(probs[s_, :pr.shape[1]].detach().cpu().numpy(), pr[0].detach().numpy(), 1e-6) < TOL_OUT
+        if pr.shape[1] < probs.shape[1]:
+            assert float(probs[s_, pr.shape[1]:].abs().max()) == 0.0          # padding exactly 0
+        tot = tot + (pr[0] * cot[s_, :pr.shape[1]].double()).sum()
+    tot.backward()
+    tol = 1e-4 if precision == "fp32" else 3e-4
+    assert H.elem_err(vg.grad.cpu().numpy(), vr.grad.numpy()) < tol
+    for n, p_ in ep.named_parameters():
+        ref = P["edge_predictor." + n].grad
+        if ref is None:
+            assert p_.grad is None, n
+        else:
+            assert H.elem_err(p_.grad.cpu().numpy(), ref.numpy()) < tol, n
+    with pytest.raises(ValueError):
+        EdgePredictor(9, 64, 2)
+
+
 @pytest.mark.parametrize("V", [0, 1])
 def test_edge_degenerate_counts_raise_like_reference(V):
     from models.EdgePredictor import EdgePredictor

@@ -18,22 +18,22 @@ namespace {
 // ---- vertex rows: gather counts[s] leading vertices of each sample ------------
 __global__ __launch_bounds__(256) void gather_verts_kernel(const float* __restrict__ verts, long s_stride, long v_stride,
                                                             const int32_t* __restrict__ voff,
-                                                            const int32_t* __restrict__ vsample, int Rv,
+                                                            const int32_t* __restrict__ vsample, int Rv, int vd,
                                                             float* __restrict__ cv) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Rv * 3) return;
-    const int r = idx / 3, k = idx % 3;
+    if (idx >= Rv * vd) return;
+    const int r = idx / vd, k = idx % vd;
     const int s = vsample[r];
     cv[idx] = verts[(long)s * s_stride + (long)(r - voff[s]) * v_stride + k];
 }
 
 __global__ __launch_bounds__(256) void scatter_dverts_kernel(const float* __restrict__ dcv, const int32_t* __restrict__ voff,
-                                                              int B, int V, float* __restrict__ dverts) {
+                                                              int B, int V, int vd, float* __restrict__ dverts) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * V * 3) return;
-    const int k = idx % 3, v = (idx / 3) % V, s = idx / (3 * V);
+    if (idx >= B * V * vd) return;
+    const int k = idx % vd, v = (idx / vd) % V, s = idx / (vd * V);
     const int n = voff[s + 1] - voff[s];
-    dverts[idx] = v < n ? dcv[(size_t)(voff[s] + v) * 3 + k] : 0.f;
+    dverts[idx] = v < n ? dcv[(size_t)(voff[s] + v) * vd + k] : 0.f;
 }
 
 // ---- pair combine forward: one wave per edge row --------------------------------
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
                                                         float* __restrict__ rs, float* __restrict__ delta,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int act, uint32_t seed, uint32_t thresh, float dscale,
-                                                        float* __restrict__ h_sx8) {
+                                                        float* __restrict__ h_sx8, int vd) {
     constexpr int EPW = 8;
     const int lane = threadIdx.x & 63;
     const int e0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW;
@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(const float* __restrict__
             i = 0; j = 1;
         }
         const int ri = vbase + i, rj = vbase + j;
-        const float dx = cv[ri * 3] - cv[rj * 3], dy = cv[ri * 3 + 1] - cv[rj * 3 + 1], dz = cv[ri * 3 + 2] - cv[rj * 3 + 2];
-        const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+        float dl2 = 0.f;                                   // |c_i - c_j|^2 over the vd coordinates (vd = 3: x, y, z in this order)
+        for (int k = 0; k < vd; ++k) { const float d = cv[ri * vd + k] - cv[rj * vd + k]; dl2 = fmaf(d, d, dl2); }
+        const float dl = sqrtf(dl2);
         f32x4 val[NS];
         float sum = 0.f;
 #pragma unroll
@@ -160,8 +161,9 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
                                                         const int32_t* __restrict__ vsample, int H,
                                                         float* __restrict__ dPa, float* __restrict__ dPb,
                                                         float* __restrict__ dcv, const float* __restrict__ wcoord,
-                                                        int wcoord_stride) {
-    extern __shared__ __attribute__((aligned(16))) float red[];     // [2][H] + [4][3] + [4][3]
+                                                        int wcoord_stride, int vd) {
+    constexpr int MAXD = 8;                                          // coordinates per vertex (host-checked)
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [2][H] + [4][MAXD] + [4][MAXD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x;
     const int s = vsample[r];
@@ -176,8 +178,9 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
 #pragma unroll
             for (int k = 0; k < 4; ++k) wv[t][k] = wd[(size_t)(c + k) * wd_stride];
     }
-    const float cx = cv[r * 3], cy = cv[r * 3 + 1], cz = cv[r * 3 + 2];
-    float gx = 0.f, gy = 0.f, gz = 0.f;
+    float cme[MAXD], gc[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) { cme[k] = k < vd ? cv[r * vd + k] : 0.f; gc[k] = 0.f; }
     // incident edges: other = 0..nv-1 except me; 4 waves interleave
     for (int other = wave; other < nv; other += 4) {
         if (other == me) continue;
@@ -197,11 +200,12 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
         dot = wf3d_wave_sum(dot);
         const float w = dot / delta[e];
         const int ro = v0 + other;
-        gx += w * (cx - cv[ro * 3]); gy += w * (cy - cv[ro * 3 + 1]); gz += w * (cz - cv[ro * 3 + 2]);
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) if (k < vd) gc[k] += w * (cme[k] - cv[ro * vd + k]);
     }
     float* ra = red;
     float* rb = red + H;
-    float* rc = red + 2 * H;
+    float* rc = red + 2 * H;                    // [4 waves][MAXD]
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -214,32 +218,43 @@ __global__ __launch_bounds__(256) void pair_bwd_kernel(const float* __restrict__
                     *reinterpret_cast<f32x4*>(rb + c) = y;
                 }
             }
-            if (lane == 0) { rc[w * 3] = gx; rc[w * 3 + 1] = gy; rc[w * 3 + 2] = gz; }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < MAXD; ++k) rc[w * MAXD + k] = gc[k];
+            }
         }
         __syncthreads();
     }
     // the coordinate columns of the first edge Linear: pre also held c_i . Wc^T + c_j . Wd^T, so this vertex's coordinates
     // receive dPa[r] . Wc + dPb[r] . Wd — two [rows, H] x [H, 3] products that would otherwise be separate launches
-    float qx = 0.f, qy = 0.f, qz = 0.f;
+    float qc[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) qc[k] = 0.f;
     for (int c = threadIdx.x; c < H; c += 256) {
         const float a = ra[c], b = rb[c];
         dPa[(size_t)r * H + c] = a;
         dPb[(size_t)r * H + c] = b;
         if (wcoord) {
-            const float* w = wcoord + (size_t)c * wcoord_stride;
-            qx += a * w[0] + b * w[3]; qy += a * w[1] + b * w[4]; qz += a * w[2] + b * w[5];
+            const float* w = wcoord + (size_t)c * wcoord_stride;          // [Wc[c, 0..vd) | Wd[c, 0..vd)]
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) if (k < vd) qc[k] += a * w[k] + b * w[vd + k];
         }
     }
-    float* rq = red + 2 * H + 12;
+    float* rq = red + 2 * H + 4 * MAXD;
     if (wcoord) {
-        qx = wf3d_wave_sum(qx); qy = wf3d_wave_sum(qy); qz = wf3d_wave_sum(qz);
-        if (lane == 0) { rq[wave * 3] = qx; rq[wave * 3 + 1] = qy; rq[wave * 3 + 2] = qz; }
+#pragma unroll
+        for (int k = 0; k < MAXD; ++k) qc[k] = wf3d_wave_sum(qc[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) rq[wave * MAXD + k] = qc[k];
+        }
         __syncthreads();
     }
-    if (threadIdx.x < 3) {
-        float v = (rc[threadIdx.x] + rc[3 + threadIdx.x]) + (rc[6 + threadIdx.x] + rc[9 + threadIdx.x]);
-        if (wcoord) v += (rq[threadIdx.x] + rq[3 + threadIdx.x]) + (rq[6 + threadIdx.x] + rq[9 + threadIdx.x]);
-        dcv[r * 3 + threadIdx.x] = v;
+    if ((int)threadIdx.x < vd) {
+        const int k = threadIdx.x;
+        float v = (rc[k] + rc[MAXD + k]) + (rc[2 * MAXD + k] + rc[3 * MAXD + k]);
+        if (wcoord) v += (rq[k] + rq[MAXD + k]) + (rq[2 * MAXD + k] + rq[3 * MAXD + k]);
+        dcv[r * vd + k] = v;
     }
 }
 
@@ -295,22 +310,22 @@ __global__ __launch_bounds__(256) void vertex_finalize_bwd_kernel(const float* _
 }  // namespace
 
 extern "C" int wf3d_edge_gather_verts(const float* verts, long sample_stride, long vertex_stride, const int32_t* voff,
-                                      const int32_t* vsample, int Rv, float* cv, void* stream) {
-    WF3D_CHECK(Rv >= 0, WF3D_ERR_ARG, "wf3d_edge_gather_verts: bad Rv");
+                                      const int32_t* vsample, int Rv, int vd, float* cv, void* stream) {
+    WF3D_CHECK(Rv >= 0 && vd >= 1 && vd <= 8, WF3D_ERR_ARG, "wf3d_edge_gather_verts: bad Rv, or vertex_dim not in 1..8");
     if (Rv == 0) return WF3D_OK;
     WF3D_CHECK(verts && voff && vsample && cv, WF3D_ERR_ARG, "wf3d_edge_gather_verts: null pointer");
-    hipLaunchKernelGGL(gather_verts_kernel, dim3(wf3d_cdiv((long)Rv * 3, 256)), dim3(256), 0, (hipStream_t)stream, verts,
-                       sample_stride, vertex_stride, voff, vsample, Rv, cv);
+    hipLaunchKernelGGL(gather_verts_kernel, dim3(wf3d_cdiv((long)Rv * vd, 256)), dim3(256), 0, (hipStream_t)stream, verts,
+                       sample_stride, vertex_stride, voff, vsample, Rv, vd, cv);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
 
-extern "C" int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V, float* dverts, void* stream) {
-    WF3D_CHECK(B >= 0 && V >= 0, WF3D_ERR_ARG, "wf3d_edge_scatter_dverts: bad dims");
+extern "C" int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, int B, int V, int vd, float* dverts, void* stream) {
+    WF3D_CHECK(B >= 0 && V >= 0 && vd >= 1 && vd <= 8, WF3D_ERR_ARG, "wf3d_edge_scatter_dverts: bad dims");
     if (B * V == 0) return WF3D_OK;
     WF3D_CHECK(voff && dverts, WF3D_ERR_ARG, "wf3d_edge_scatter_dverts: null pointer");
-    hipLaunchKernelGGL(scatter_dverts_kernel, dim3(wf3d_cdiv((long)B * V * 3, 256)), dim3(256), 0, (hipStream_t)stream,
-                       dcv, voff, B, V, dverts);
+    hipLaunchKernelGGL(scatter_dverts_kernel, dim3(wf3d_cdiv((long)B * V * vd, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dcv, voff, B, V, vd, dverts);
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
 }
@@ -318,19 +333,19 @@ extern "C" int wf3d_edge_scatter_dverts(const float* dcv, const int32_t* voff, i
 static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
                          const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
                          float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
-                         float drop_p, uint32_t drop_seed, void* h_sx8, void* stream);
+                         float drop_p, uint32_t drop_seed, void* h_sx8, int vd, void* stream);
 
 extern "C" int wf3d_edge_pair_fwd(const float* Pa, const float* Pb, const float* cv, const float* wdelta,
                                   int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample,
-                                  int Re, int H, float eps, float* pre, float* mu, float* rs, float* delta,
+                                  int Re, int H, int vd, float eps, float* pre, float* mu, float* rs, float* delta,
                                   void* stream) {
     return pair_fwd_impl(Pa, Pb, cv, wdelta, wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, nullptr,
-                         nullptr, 0, 0.f, 0u, nullptr, stream);
+                         nullptr, 0, 0.f, 0u, nullptr, vd, stream);
 }
 
 extern "C" int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const float* cv, const float* wdelta,
                                      int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* esample,
-                                     int Re, int H, float eps, float* pre, float* mu, float* rs, float* delta,
+                                     int Re, int H, int vd, float eps, float* pre, float* mu, float* rs, float* delta,
                                      const float* gamma, const float* beta, int act, float drop_p, uint32_t drop_seed,
                                      void* h_sx8, void* stream) {
     WF3D_CHECK(gamma && beta && h_sx8, WF3D_ERR_ARG, "wf3d_edge_pair_fwd_ln: null pointer");
@@ -338,16 +353,16 @@ extern "C" int wf3d_edge_pair_fwd_ln(const float* Pa, const float* Pb, const flo
                WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_fwd_ln: needs hidden %% 8 == 0 and 16-byte aligned pointers");
     WF3D_CHECK(act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f, WF3D_ERR_ARG, "wf3d_edge_pair_fwd_ln: bad act/drop");
     return pair_fwd_impl(Pa, Pb, cv, wdelta, wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, gamma, beta,
-                         act, drop_p, drop_seed, h_sx8, stream);
+                         act, drop_p, drop_seed, h_sx8, vd, stream);
 }
 
 static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, const float* wdelta, int wdelta_stride,
                          const int32_t* voff, const int32_t* eoff, const int32_t* esample, int Re, int H, float eps,
                          float* pre, float* mu, float* rs, float* delta, const float* gamma, const float* beta, int act,
-                         float drop_p, uint32_t drop_seed, void* h_sx8, void* stream) {
+                         float drop_p, uint32_t drop_seed, void* h_sx8, int vd, void* stream) {
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dscale = 1.0f / (1.0f - drop_p);
-    WF3D_CHECK(Re >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_fwd: bad dims");
+    WF3D_CHECK(Re >= 0 && H > 0 && vd >= 1 && vd <= 8, WF3D_ERR_ARG, "wf3d_edge_pair_fwd: bad dims (vertex_dim must be 1..8)");
     WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_fwd: hidden %d must be a multiple of 4, <= 2048", H);
     if (Re == 0) return WF3D_OK;
     WF3D_CHECK(Pa && Pb && cv && wdelta && voff && eoff && esample && (pre || h_sx8) && mu && rs && delta, WF3D_ERR_ARG,
@@ -357,7 +372,7 @@ static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, cons
 #define WF3D_PF(NS_)                                                                                                 \
     hipLaunchKernelGGL((pair_fwd_kernel<NS_>), dim3(wf3d_cdiv(Re, 4 * 8)), dim3(256), 0, st, Pa, Pb, cv, wdelta,           \
                        wdelta_stride, voff, eoff, esample, Re, H, eps, pre, mu, rs, delta, gamma, beta, act, drop_seed,    \
-                       thresh, dscale, (float*)h_sx8)
+                       thresh, dscale, (float*)h_sx8, vd)
     if (ns <= 1) WF3D_PF(1); else if (ns <= 2) WF3D_PF(2); else if (ns <= 4) WF3D_PF(4); else WF3D_PF(8);
 #undef WF3D_PF
     WF3D_LAUNCH_CHECK();
@@ -366,20 +381,20 @@ static int pair_fwd_impl(const float* Pa, const float* Pb, const float* cv, cons
 
 extern "C" int wf3d_edge_pair_bwd(const float* dpre, const float* delta, const float* cv, const float* wdelta,
                                   int wdelta_stride, const int32_t* voff, const int32_t* eoff, const int32_t* vsample,
-                                  int Rv, int H, float* dPa, float* dPb, float* dcv, const float* wcoord,
+                                  int Rv, int H, int vd, float* dPa, float* dPb, float* dcv, const float* wcoord,
                                   int wcoord_stride, void* stream) {
-    WF3D_CHECK(Rv >= 0 && H > 0, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: bad dims");
-    WF3D_CHECK(!wcoord || wcoord_stride >= 6, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: wcoord rows hold [Wc | Wd] = 6 floats");
+    WF3D_CHECK(Rv >= 0 && H > 0 && vd >= 1 && vd <= 8, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: bad dims (vertex_dim must be 1..8)");
+    WF3D_CHECK(!wcoord || wcoord_stride >= 2 * vd, WF3D_ERR_ARG, "wf3d_edge_pair_bwd: wcoord rows hold [Wc | Wd] = 2 x vertex_dim floats");
     WF3D_CHECK(H % 4 == 0 && H <= 2048, WF3D_ERR_UNSUPPORTED, "wf3d_edge_pair_bwd: hidden %d must be a multiple of 4, <= 2048", H);
     if (Rv == 0) return WF3D_OK;
     WF3D_CHECK(dpre && delta && cv && wdelta && voff && eoff && vsample && dPa && dPb && dcv, WF3D_ERR_ARG,
                "wf3d_edge_pair_bwd: null pointer");
     const int ns = wf3d_cdiv(H, 256);
-    const size_t lds = ((size_t)2 * H + 32) * sizeof(float);
+    const size_t lds = ((size_t)2 * H + 64) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define WF3D_PB(NS_)                                                                                                 \
     hipLaunchKernelGGL((pair_bwd_kernel<NS_>), dim3(Rv), dim3(256), lds, st, dpre, delta, cv, wdelta, wdelta_stride,   \
-                       voff, eoff, vsample, H, dPa, dPb, dcv, wcoord, wcoord_stride)
+                       voff, eoff, vsample, H, dPa, dPb, dcv, wcoord, wcoord_stride, vd)
     if (ns <= 1) WF3D_PB(1); else if (ns <= 2) WF3D_PB(2); else if (ns <= 4) WF3D_PB(4); else WF3D_PB(8);
 #undef WF3D_PB
     WF3D_LAUNCH_CHECK();

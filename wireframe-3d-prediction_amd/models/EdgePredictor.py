@@ -3,7 +3,7 @@
 Module tree and state_dict keys follow reference models/EdgePredictor.py:31-68
 (including `spatial_proj`, which the reference builds but never uses — kept for
 RNG-order and state_dict compatibility).  forward() accepts a
-padded batch [B, V, 3]; `forward_ragged` runs samples with different vertex
+padded batch [B, V, vertex_dim]; `forward_ragged` runs samples with different vertex
 counts in one pass, which is how PointCloudToWireframe replaces the reference's
 serial per-sample loop."""
 import torch
@@ -16,8 +16,8 @@ from wf3d.functional import EdgeFn, edge_index_lists
 class EdgePredictor(nn.Module):
     def __init__(self, vertex_dim=3, hidden_dim=512, num_heads=8):
         super().__init__()
-        if vertex_dim != 3:
-            raise ValueError("the HIP edge head is built for 3-D vertex coordinates (reference default)")
+        if not 1 <= vertex_dim <= 8:
+            raise ValueError("the HIP edge head takes 1..8 coordinates per vertex (reference default: 3)")
         h = hidden_dim
         self.vertex_proj = nn.Sequential(
             nn.Linear(vertex_dim, h // 2), nn.LayerNorm(h // 2), nn.GELU(),

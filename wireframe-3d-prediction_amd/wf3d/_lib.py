@@ -130,9 +130,9 @@ SIGNATURES = {
                                    c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wf3d_vertex_finalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "wf3d_edge_gather_verts": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p,
+    "wf3d_edge_gather_verts": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                        c_void_p]),
-    "wf3d_edge_scatter_dverts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "wf3d_edge_scatter_dverts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_attn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p,
                               c_void_p]),
     "wf3d_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
@@ -142,12 +142,12 @@ SIGNATURES = {
                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_u32, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wf3d_edge_pair_fwd_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                      c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                       ctypes.c_uint32, c_void_p, c_void_p]),
     "wf3d_edge_pair_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wf3d_edge_pair_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                   c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "wf3d_edge_prob_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wf3d_loss_cost_matrix": (c_int, [c_void_p, ctypes.c_long, ctypes.c_long, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                       c_int, c_void_p, c_void_p]),

@@ -477,10 +477,17 @@ class EdgeFn(torch.autograd.Function):
         qkv = ops.gemm(f, Aw, NT, bias=Ab, x3=x3)
         cx, lse = ops.attn_fwd(qkv, meta, H, heads, pa_, sd[1])
         Fm = ops.gemm(cx, Ow, NT, bias=Ob, addend=f, x3=x3)              # residual (EdgePredictor.py:114)
-        Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + 3], M0w[:, 2 * H + 3:2 * H + 6]
-        # the coordinate columns ride on the two GEMMs as a rank-3 epilogue term (exact fp32)
-        Pa = ops.gemm(Fm, Wa, NT, bias=M0b, x3=x3, lowrank=(cv, Wc))
-        Pb = ops.gemm(Fm, Wb, NT, x3=x3, lowrank=(cv, Wd))
+        vd = cv.shape[1]                                   # coordinates per vertex (EdgePredictor(vertex_dim=...): 3 in the model)
+        Wa, Wb, Wc, Wd = M0w[:, :H], M0w[:, H:2 * H], M0w[:, 2 * H:2 * H + vd], M0w[:, 2 * H + vd:2 * H + 2 * vd]
+        if vd <= 4:
+            # the coordinate columns ride on the two GEMMs as a rank-vd epilogue term (exact fp32)
+            Pa = ops.gemm(Fm, Wa, NT, bias=M0b, x3=x3, lowrank=(cv, Wc))
+            Pb = ops.gemm(Fm, Wb, NT, x3=x3, lowrank=(cv, Wd))
+        else:
+            Pa = ops.gemm(Fm, Wa, NT, bias=M0b, x3=x3)
+            ops.gemm(cv, Wc, NT, out=Pa, accumulate=True)
+            Pb = ops.gemm(Fm, Wb, NT, x3=x3)
+            ops.gemm(cv, Wd, NT, out=Pb, accumulate=True)
         # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
         split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
         if split:
@@ -590,15 +597,16 @@ class EdgeFn(torch.autograd.Function):
         else:
             dpre, G[14], G[15], wsum = ops.ln_act_bwd_wsum(dh1, pre, delta, mu0, rs0, M1g, M1b, ACT_GELU, p1_, sd[2], inplace=True)
         # split first layer backward
+        vd = cv.shape[1]
         dW0 = torch.empty_like(M0w)           # every column is written below: Wa | Wb | Wc | Wd | w_delta
-        dW0[:, 2 * H + 6].copy_(wsum)
+        dW0[:, 2 * H + 2 * vd].copy_(wsum)
         dPa, dPb, dcv = ops.edge_pair_bwd(dpre, delta, cv, M0w, meta, coord=True)     # dcv includes dPa·Wc + dPb·Wd
 
         def first_layer_leaves():
             ops.gemm(dPa, Fm, TN, out=dW0[:, :H], x3=x3)
             ops.gemm(dPb, Fm, TN, out=dW0[:, H:2 * H], x3=x3)
-            ops.gemm(dPa, cv, TN, out=dW0[:, 2 * H:2 * H + 3])
-            ops.gemm(dPb, cv, TN, out=dW0[:, 2 * H + 3:2 * H + 6])
+            ops.gemm(dPa, cv, TN, out=dW0[:, 2 * H:2 * H + vd])
+            ops.gemm(dPb, cv, TN, out=dW0[:, 2 * H + vd:2 * H + 2 * vd])
             return ops.colsum(dPa)
         G[13] = lv.run(first_layer_leaves, dPa, dPb, Fm, cv, dW0)
         G[12] = dW0

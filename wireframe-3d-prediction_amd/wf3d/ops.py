@@ -403,19 +403,21 @@ class EdgeMeta:
 
 
 def edge_gather_verts(verts, meta):
-    """verts [B, V, 3] (any strides with unit inner stride) -> cv [Rv, 3]."""
+    """verts [B, V, d] (any strides with unit inner stride; d = vertex_dim, 1..8) -> cv [Rv, d]."""
     _need_cuda(verts)
     if verts.stride(2) != 1:
         raise RuntimeError("wf3d.edge_gather_verts: inner stride must be 1")
-    cv = torch.empty(meta.Rv, 3, dtype=torch.float32, device=verts.device)
+    d = verts.shape[2]
+    cv = torch.empty(meta.Rv, d, dtype=torch.float32, device=verts.device)
     check(_lib.load().wf3d_edge_gather_verts(_p(verts), verts.stride(0), verts.stride(1), _p(meta.voff),
-                                             _p(meta.vsample), meta.Rv, _p(cv), _stream()), "edge_gather_verts")
+                                             _p(meta.vsample), meta.Rv, d, _p(cv), _stream()), "edge_gather_verts")
     return cv
 
 
 def edge_scatter_dverts(dcv, meta, B, V):
-    out = torch.empty(B, V, 3, dtype=torch.float32, device=dcv.device)
-    check(_lib.load().wf3d_edge_scatter_dverts(_p(dcv), _p(meta.voff), B, V, _p(out), _stream()), "edge_scatter_dverts")
+    d = dcv.shape[1]
+    out = torch.empty(B, V, d, dtype=torch.float32, device=dcv.device)
+    check(_lib.load().wf3d_edge_scatter_dverts(_p(dcv), _p(meta.voff), B, V, d, _p(out), _stream()), "edge_scatter_dverts")
     return out
 
 
@@ -442,15 +444,15 @@ _wdelta_cache = [None, -1, None]       # (weight tensor, its version, contiguous
 
 
 def _wdelta(W0, H):
-    """Distance column of edge_mlp.0.weight, gathered once into a contiguous vector (a strided
-    per-lane gather of it inside the pair kernels costs 512 uncoalesced loads per edge row).
+    """Distance column (the last one) of edge_mlp.0.weight [H, 2H + 2d + 1], gathered once into a contiguous vector (a
+    strided per-lane gather of it inside the pair kernels costs 512 uncoalesced loads per edge row).
     Forward and backward of one step see the same weight version and share the copy."""
-    if tuple(W0.shape) != (H, 2 * H + 7):
-        raise RuntimeError("wf3d: edge_mlp.0.weight must be [H, 2H+7]")
+    if W0.dim() != 2 or W0.shape[0] != H or W0.shape[1] < 2 * H + 3 or (W0.shape[1] - 2 * H - 1) % 2:
+        raise RuntimeError("wf3d: edge_mlp.0.weight must be [H, 2H + 2*vertex_dim + 1]")
     c = _wdelta_cache
     if c[0] is W0 and c[1] == W0._version:
         return c[2], 1
-    col = W0.detach()[:, 2 * H + 6].contiguous()
+    col = W0.detach()[:, W0.shape[1] - 1].contiguous()
     c[0], c[1], c[2] = W0, W0._version, col
     return col, 1
 
@@ -468,14 +470,14 @@ def edge_pair_fwd(Pa, Pb, cv, W0, meta, eps=LN_EPS, ln=None, keep_pre=True):
     delta = torch.empty(meta.Re, dtype=torch.float32, device=dev)
     if ln is None:
         check(_lib.load().wf3d_edge_pair_fwd(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
-                                             _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
+                                             _p(meta.esample), meta.Re, H, cv.shape[1], eps, _p(pre), _p(mu), _p(rs), _p(delta),
                                              _stream()), "edge_pair_fwd")
         return pre, mu, rs, delta
     gamma, beta, act, drop_p, seed = ln
     _need_cuda(gamma, beta)
     h = torch.empty(meta.Re, H, dtype=torch.float32, device=dev)
     check(_lib.load().wf3d_edge_pair_fwd_ln(_p(Pa), _p(Pb), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
-                                            _p(meta.esample), meta.Re, H, eps, _p(pre), _p(mu), _p(rs), _p(delta),
+                                            _p(meta.esample), meta.Re, H, cv.shape[1], eps, _p(pre), _p(mu), _p(rs), _p(delta),
                                             _p(gamma), _p(beta), act, float(drop_p), int(seed) & 0xFFFFFFFF, _p(h),
                                             _stream()), "edge_pair_fwd_ln")
     return pre, mu, rs, delta, h
@@ -501,19 +503,20 @@ def edge_pair_ln_bwd(dh, Pa, Pb, delta, W0, meta, mu, rs, gamma, beta, act, drop
 
 
 def edge_pair_bwd(dpre, delta, cv, W0, meta, coord=False):
-    """coord=True: dcv also receives dPa·Wc + dPb·Wd (the coordinate columns 2H..2H+5 of W0)."""
+    """coord=True: dcv also receives dPa·Wc + dPb·Wd (the coordinate columns 2H..2H+2d-1 of W0, d = cv.shape[1])."""
     _need_cuda(dpre, delta, cv, W0)
     H = dpre.shape[1]
+    d = cv.shape[1]
     wd, stride = _wdelta(W0, H)
-    wc = W0[:, 2 * H:2 * H + 6] if coord else None
-    if coord and (W0.dim() != 2 or W0.shape[1] < 2 * H + 6 or W0.stride(1) != 1):
-        raise RuntimeError("wf3d.edge_pair_bwd: W0 must be [H, >= 2H+6] with unit inner stride")
+    wc = W0[:, 2 * H:2 * H + 2 * d] if coord else None
+    if coord and (W0.dim() != 2 or W0.shape[1] < 2 * H + 2 * d or W0.stride(1) != 1):
+        raise RuntimeError("wf3d.edge_pair_bwd: W0 must be [H, >= 2H + 2*vertex_dim] with unit inner stride")
     dev = dpre.device
     dPa = torch.empty(meta.Rv, H, dtype=torch.float32, device=dev)
     dPb = torch.empty(meta.Rv, H, dtype=torch.float32, device=dev)
-    dcv = torch.empty(meta.Rv, 3, dtype=torch.float32, device=dev)
+    dcv = torch.empty(meta.Rv, d, dtype=torch.float32, device=dev)
     check(_lib.load().wf3d_edge_pair_bwd(_p(dpre), _p(delta), _p(cv), _p(wd), stride, _p(meta.voff), _p(meta.eoff),
-                                         _p(meta.vsample), meta.Rv, H, _p(dPa), _p(dPb), _p(dcv), _p(wc),
+                                         _p(meta.vsample), meta.Rv, H, d, _p(dPa), _p(dPb), _p(dcv), _p(wc),
                                          W0.stride(0) if coord else 0, _stream()),
           "edge_pair_bwd")
     return dPa, dPb, dcv
