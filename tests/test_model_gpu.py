@@ -503,6 +503,29 @@ def test_second_backward_raises_a_clear_error():
         loss.backward()
 
 
+def test_retain_graph_is_served_when_the_saved_activations_are_kept():
+    """wf3d.config.RETAIN_SAVED = True: the stages keep their saved activations, so backward(retain_graph=True) followed by
+    a second backward works as with the reference's autograd — the second pass accumulates the same gradients again."""
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    from wf3d import config
+    torch.manual_seed(2)
+    model = PointCloudToWireframe(8, 6).to(dev()).set_dropout(0.0)
+    model.train()
+    old = config.RETAIN_SAVED
+    config.RETAIN_SAVED = True
+    try:
+        out = model(torch.randn(2, 64, 8, device=dev()), torch.tensor([6, 4]))
+        loss = out["vertices"].sum() + out["edge_probs"].sum()
+        loss.backward(retain_graph=True)
+        g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        loss.backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-6, atol=1e-9), n
+    finally:
+        config.RETAIN_SAVED = old
+
+
 def test_inplace_parameter_update_between_forward_and_backward_is_reported():
     """The stages keep their parameters as plain references; an optimizer step (or any in-place write) between the
     forward and its backward must raise, as autograd does for saved tensors — not differentiate against new values."""

@@ -41,3 +41,8 @@ EDGE_X3 = os.environ.get("WF3D_EDGE_X3", "0") != "0"
 
 # Edge head: store the first edge layer's pre-activation even when backward could rebuild it (A/B switch, WF3D_KEEP_PRE=1).
 KEEP_PRE = os.environ.get("WF3D_KEEP_PRE", "0") != "0"
+
+# The stages release their saved activations (2.7 GB at cfg2) at the end of their backward, so a second backward through
+# the same graph (retain_graph=True, which the reference's autograd serves) raises.  RETAIN_SAVED = True keeps them
+# until the graph itself is freed.
+RETAIN_SAVED = os.environ.get("WF3D_RETAIN_SAVED", "0") != "0"

@@ -25,7 +25,8 @@ def _saved(ctx):
     instead of failing on a None unpack."""
     if ctx.saved is None:
         raise RuntimeError("wf3d: backward through this graph a second time — the stage's saved activations were "
-                           "released by the first backward (retain_graph is not supported); re-run the forward")
+                           "released by the first backward; re-run the forward, or set wf3d.config.RETAIN_SAVED = True "
+                           "(WF3D_RETAIN_SAVED=1) before the forward to keep them for backward(retain_graph=True)")
     return ctx.saved
 
 
@@ -251,7 +252,8 @@ class EncoderFn(torch.autograd.Function):
             if i > 0 and dz_s is not None and h_prev_s is not None and ops.gemm_split_tn_ok(dz_s, h_prev_s):
                 # wgrad dW = dz^T · h_prev straight from the reduction-major sx8 operands (transposing LDS reads)
                 grads[4 * i] = ops.gemm_split_tn(dz_s, h_prev_s)
-                hs[i - 1] = None
+                if not config.RETAIN_SAVED:
+                    hs[i - 1] = None
             elif i > 0 and dz_s is not None and _split_ok(M, K, split) and M % 8 == 0:
                 # same through materialised transposes (shapes the TN kernel does not tile)
                 grads[4 * i] = ops.gemm_split(ops.split_transpose(dz_s, in_sx8=True), ops.split_transpose(a_prev, pro_prev))
@@ -266,7 +268,8 @@ class EncoderFn(torch.autograd.Function):
                 dx = ops.gemm(dz, W, NN).view(B, N, -1)           # at layer 0 dz is always the fp32 tensor
             del dz, dz_s
             dz = dz_s = None
-        ctx.saved = None
+        if not config.RETAIN_SAVED:
+            ctx.saved = None
         return (dx, None, None, *grads)
 
 
@@ -320,7 +323,8 @@ class FusionFn(torch.autograd.Function):
             G[4], dh = _lin_bwd(dz, f0, F[4], Pro(ACT_RELU, s0[0], s0[1], F[2], F[3]))
             dz, G[2], G[3], G[1] = ops.ln_act_bwd(dh, f0, s0[0], s0[1], F[2], F[3], ACT_RELU, inplace=True)
             G[0], dpooled = _lin_bwd(dz, pooled, F[0], None)
-        ctx.saved = None
+        if not config.RETAIN_SAVED:
+            ctx.saved = None
         return (dpooled, *G)
 
 
@@ -417,7 +421,8 @@ class VertexFn(torch.autograd.Function):
                 Wpp = params[22]
                 (G[22], G[23], sl), = sk.bwd(B, sk.Bwd(de, Wpp, pooled))
                 dupooled, *_ = sk.reduce(B, Wpp.shape[1], [sl])
-            ctx.saved = None
+            if not config.RETAIN_SAVED:
+                ctx.saved = None
             return (de, dupooled, None, None, *G)
         G[17] = ops.colsum(do)
         G[16], dd = _lin_bwd(do, d, Wf, None)
@@ -444,7 +449,8 @@ class VertexFn(torch.autograd.Function):
             G[23] = ops.colsum(de)
             G[22] = ops.gemm(de, pooled, TN)
             dupooled = ops.gemm(de, Wpp, NN)
-        ctx.saved = None
+        if not config.RETAIN_SAVED:
+            ctx.saved = None
         return (de, dupooled, None, None, *G)
 
 
@@ -629,7 +635,8 @@ class EdgeFn(torch.autograd.Function):
         ops.gemm(dza, P0w, NN, out=dcv, accumulate=True)
         lv.join(G[20], G[16], G[13], dW0, G[11], G[10], G[9], G[8], G[4], G[0])
         dverts = ops.edge_scatter_dverts(dcv, meta, B, V)
-        ctx.saved = None
+        if not config.RETAIN_SAVED:
+            ctx.saved = None
         return (dverts, None, None, None, None, None, *G)
 
 
