@@ -211,6 +211,28 @@ def cpu_baseline(model, cfg, N, V, seconds_budget=25.0):
                       f"median {med * 1e3:.0f} ms/step, dropout 0"}
 
 
+def power_probe(ops, device, seconds=1.2):
+    """The dominant GEMM shape (131072 x 1024 -> 2048) in a loop under the board-power sensor, and the vendor library's
+    plain bf16 GEMM of the same shape beside it: what the MFMA pipes deliver under this board's power cap."""
+    from wf3d import telemetry
+    hw = telemetry.hwmon_dir(device.index or 0)
+    M, K, N = 131072, 1024, 2048
+    x, w = torch.randn(M, K, device=device), torch.randn(N, K, device=device)
+    X, W = ops.split_rows(x), ops.split_rows(w)
+    out = torch.empty(M, N, device=device)
+    fl = 2.0 * M * K * N
+    t, watts, ghz = telemetry.run_sampled(lambda: ops.gemm_split(X, W, out=out), hw, seconds)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    ob = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    del x, w
+    tl, lwatts, lghz = telemetry.run_sampled(lambda: torch.matmul(xb, wb.t(), out=ob), hw, seconds)
+    return {"shape": f"{M} x {K} -> {N}, normal random operands", "board_w": watts, "cap_w": telemetry.power_cap_watts(hw),
+            "sclk_ghz": ghz, "us": t * 1e6, "executed_mfma_tflops": 3.0 * fl / t / 1e12,
+            "library_bf16_gemm": {"what": "torch.matmul(bf16, bf16) of the same shape (hipBLASLt), one MFMA per product",
+                                  "us": tl * 1e6, "mfma_tflops": fl / tl / 1e12, "board_w": lwatts, "sclk_ghz": lghz},
+            "sensor": hw or "hwmon not visible (power fields null)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the board-power / library-GEMM yardstick after the timed region")
     ap.add_argument("--no-op-timers", action="store_true", help="diagnostic: no per-op HIP events (roofline blocks become empty)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
@@ -352,6 +375,8 @@ def main():
             res["dist_backend"] = torch.distributed.get_backend()
             res["allreduce_exposed_ms"] = ex[len(ex) // 2] if ex else None
             res["allreduce_buckets_mb"] = [round(nb / 2 ** 20, 1) for _, nb in reducer.bucket_summary()]
+        if world == 1 and split and not args.no_power_probe:
+            roof["power"] = power_probe(ops, device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model, args.config, N, V)
         print(json.dumps(res), flush=True)

@@ -53,6 +53,9 @@ const char* wf3d_last_error(void);
  *       wf3d_gemm_split_tn are cut into.  1 is fastest on an idle chip; with a collective's kernels holding CUs beside
  *       the backward pass (data parallel) a launch of one workgroup per CU waits a whole extra
  *       round for its last workgroup (+67 %), 2 / 4 rounds lose 15 % / 0 % there and cost 2.5 % / 4 % otherwise.
+ *   "gemm_cus" (0 = one workgroup per CU, the default; or 8..1024, rounded down to a multiple of 8): workgroups the
+ *       persistent kernel of wf3d_gemm_split is launched with.  Its tiles are claimed, so fewer workgroups only leave
+ *       CUs to whatever else the caller runs beside it (224 of 256 CUs: +9 % time; scripts/bench_overlap.py).
  * Returns WF3D_OK, or WF3D_ERR_ARG for an unknown name or a value out of range. */
 int wf3d_set_option(const char* name, int value);
 

@@ -1,75 +1,69 @@
-"""Can the HBM-bound ln_prep of one row chunk run UNDER the MFMA-bound GEMM of the other chunk (two streams)?
-Chain: X[M,1024] -> GEMM(2048) -> ln_prep -> GEMM(1024) -> ln_prep -> GEMM(512), sequential vs two-stream pipelined."""
-import os, sys, statistics
+#!/usr/bin/env python3
+"""Does a bandwidth-bound row pass hide beside the persistent split GEMM?  The GEMM (131072 x 1024 x 1024, bias) is
+launched on `g` CUs (wf3d_set_option("gemm_cus", g)) on one stream, ln_prep / ln_act_bwd over a 131072 x 1024 block
+on a second stream right after it; both are timed alone and together."""
+import os
+import sys
+
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "wireframe-3d-prediction_amd"))
-import torch
-from wf3d import ops
+from wf3d import _lib, ops  # noqa: E402
+
 dev = torch.device("cuda:0")
-M = 131072
-torch.manual_seed(0)
-dims = [1024, 2048, 1024, 512]
-X = ops.split_rows(torch.randn(M, dims[0], device=dev))
-Ws = [ops.split_rows(torch.randn(dims[i + 1], dims[i], device=dev) * 0.03) for i in range(3)]
-gs = [torch.ones(d, device=dev) for d in dims[1:]]
-bs = [torch.zeros(d, device=dev) for d in dims[1:]]
-zs = [torch.empty(M, d, device=dev) for d in dims[1:]]
+M, K, N, D = 131072, 1024, 1024, 1024
 side = torch.cuda.Stream(dev)
+lib = _lib.load()
 
 
-def sequential(chunks):
-    rows = M // chunks
-    for c in range(chunks):
-        sl = slice(c * rows, (c + 1) * rows)
-        a = X[sl]
-        for l in range(3):
-            ops.gemm_split(a, Ws[l], out=zs[l][sl])
-            if l < 2:
-                _, _, a = ops.ln_prep(zs[l][sl], gs[l], bs[l], ops.ACT_RELU)
-
-
-def pipelined(chunks=2):
-    """main stream: all GEMMs in (layer, chunk) order; side stream: all ln_preps; events carry the dependencies."""
-    main = torch.cuda.current_stream(dev)
-    rows = M // chunks
-    keep = []
-    a = [X[c * rows:(c + 1) * rows] for c in range(chunks)]
-    for l in range(3):
-        nxt = [None] * chunks
-        for c in range(chunks):
-            sl = slice(c * rows, (c + 1) * rows)
-            if l > 0:
-                main.wait_event(a[c][1])             # ln_prep(l-1, c) done
-                ops.gemm_split(a[c][0], Ws[l], out=zs[l][sl])
-            else:
-                ops.gemm_split(a[c], Ws[l], out=zs[l][sl])
-            if l < 2:
-                ev = torch.cuda.Event(); ev.record(main)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    _, _, h = ops.ln_prep(zs[l][sl], gs[l], bs[l], ops.ACT_RELU)
-                    done = torch.cuda.Event(); done.record(side)
-                keep.append(h)
-                nxt[c] = (h, done)
-        a = nxt
-    main.wait_stream(side)
-    return keep
-
-
-def timeit(fn, n=7):
-    for _ in range(2):
-        fn()
+def run(gemm_reps, row_reps, gemm, row):
+    """elapsed (us) of: GEMM x gemm_reps on the current stream, row pass x row_reps on the side stream, started together."""
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(n):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-        del r
-    return statistics.median(ts)
+    e0, e1, s1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    side.wait_event(e0)
+    for _ in range(gemm_reps):
+        gemm()
+    e1.record()
+    with torch.cuda.stream(side):
+        for _ in range(row_reps):
+            row()
+        s1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3, e0.elapsed_time(s1) * 1e3
 
 
-for name, fn in [("sequential, 1 chunk", lambda: sequential(1)), ("sequential, 2 chunks", lambda: sequential(2)),
-                 ("two streams, 2 chunks", lambda: pipelined(2)), ("two streams, 4 chunks", lambda: pipelined(4)),
-                 ("sequential, 1 chunk", lambda: sequential(1))]:
-    print(f"{name:24s} {timeit(fn):7.3f} ms")
+def main():
+    X = ops.split_rows(torch.randn(M, K, device=dev))
+    W = ops.split_rows(torch.randn(N, K, device=dev))
+    bias = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev)
+    z = torch.randn(M, D, device=dev)
+    dh = torch.randn(M, D, device=dev)
+    gamma, beta = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    mu, rs, _ = ops.ln_prep(z, gamma, beta, 1)
+    dzs = torch.empty_like(z)
+    gemm = lambda: ops.gemm_split(X, W, bias=bias, out=out)
+    rows = {"ln_prep": lambda: ops.ln_prep(z, gamma, beta, 1),
+            "ln_act_bwd": lambda: ops.ln_act_bwd(dh, z, mu, rs, gamma, beta, 1, dz_split=dzs, want_dz=False)}
+    for f in (gemm, *rows.values()):
+        f()
+    R = 4
+    lib.wf3d_set_option(b"gemm_cus", 0)
+    tg = sorted(run(R, 0, gemm, None)[0] for _ in range(3))[1] / R
+    print(f"GEMM alone, 256 CUs: {tg:8.1f} us")
+    for name, row in rows.items():
+        tr = sorted(run(0, R, None, row)[1] for _ in range(3))[1] / R
+        print(f"{name} alone: {tr:8.1f} us   -> back to back {tg + tr:8.1f} us per (GEMM + row pass)")
+        for g in (256, 240, 224, 208, 192, 160):
+            lib.wf3d_set_option(b"gemm_cus", 0 if g == 256 else g)
+            ta = sorted(run(R, 0, gemm, None)[0] for _ in range(3))[1] / R
+            both = sorted((run(R, R, gemm, row) for _ in range(3)), key=max)[1]
+            print(f"  gemm_cus={g:3d}: GEMM alone {ta:8.1f}   together: GEMM stream {both[0] / R:8.1f}  row stream {both[1] / R:8.1f}"
+                  f"  -> {max(both) / R:8.1f} us per pair ({(tg + tr) / (max(both) / R):.3f}x)")
+        lib.wf3d_set_option(b"gemm_cus", 0)
+
+
+if __name__ == "__main__":
+    main()

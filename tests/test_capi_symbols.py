@@ -46,6 +46,8 @@ def test_set_option_validates():
     assert lib.wf3d_set_option(b"tn_rounds", 2) == 0
     assert lib.wf3d_set_option(b"tn_rounds", 1) == 0
     assert lib.wf3d_set_option(b"tn_rounds", 9) == -1 and b"1..8" in lib.wf3d_last_error()
+    assert lib.wf3d_set_option(b"gemm_cus", 224) == 0 and lib.wf3d_set_option(b"gemm_cus", 0) == 0
+    assert lib.wf3d_set_option(b"gemm_cus", 3) == -1 and b"gemm_cus" in lib.wf3d_last_error()
     assert lib.wf3d_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.wf3d_last_error()
     assert lib.wf3d_set_option(None, 1) == -1
 

@@ -169,3 +169,23 @@ def test_persistent_kernel_with_reserved_cus_in_child_process():
     assert out.returncode == 0, out.stderr[-2000:]
     rel = float([ln for ln in out.stdout.splitlines() if ln.startswith("REL")][-1].split()[1])
     assert rel < TOL_SPLIT
+
+
+@pytest.mark.parametrize("cus", [8, 200])
+def test_persistent_kernel_on_fewer_workgroups(cus):
+    """wf3d_set_option("gemm_cus", n): the claimed tiles are all computed, once each, whatever the grid."""
+    from wf3d import _lib, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(22)
+    M, K, N = 131072, 512, 1024
+    A = torch.randn(M, K, generator=g, device=dev)
+    W = torch.randn(N, K, generator=g, device=dev) * 0.05
+    As, Ws = ops.split_rows(A), ops.split_rows(W)
+    want = ops.gemm_split(As, Ws)
+    lib = _lib.load()
+    assert lib.wf3d_set_option(b"gemm_cus", cus) == 0
+    try:
+        got = ops.gemm_split(As, Ws)
+    finally:
+        lib.wf3d_set_option(b"gemm_cus", 0)
+    assert torch.equal(got, want)

@@ -1058,6 +1058,7 @@ extern "C" int wf3d_debug_stamps(unsigned long long* dst, size_t n) {
 }
 #endif
 
+static std::atomic<int> g_gemm_cus{0};           // wf3d_set_option("gemm_cus", n): workgroups of the persistent kernel (0 = one per CU)
 constexpr size_t CTL_BYTES = 2048;        // persistent kernel: 8 claim counters 64 B apart (512 B, zeroed per launch) + 256+ mailbox words
 
 extern "C" size_t wf3d_gemm_split_dma_ws_bytes(int M, int N, int K) {
@@ -1086,7 +1087,8 @@ extern "C" int wf3d_gemm_split_dma(const void* A_sx8, const void* B_sx8, float* 
     hipStream_t st = (hipStream_t)stream;
     if (variant == 6) {
         static const int persist_on = [] { const char* e = getenv("WF3D_SPLIT_PERSIST"); return e ? atoi(e) : 1; }();
-        const int cus = cu_count();
+        int cus = cu_count();
+        { const int lim = g_gemm_cus.load(std::memory_order_relaxed); if (lim >= 8 && lim < cus) cus = lim / 8 * 8; }
         // persistent form: full tiles, one pass over K, plain (non-accumulating) 16-B stores
         if (persist_on && p.ksplit == 1 && !accumulate && M % 256 == 0 && N % 256 == 0 && K / SBK >= 8 && K % (2 * SBK) == 0 &&
             ws != nullptr && ws_bytes >= CTL_BYTES && (uintptr_t)ws % 64 == 0 && cus <= 384 && cus >= 8 && cus % 8 == 0 &&
@@ -1123,6 +1125,11 @@ extern "C" int wf3d_set_option(const char* name, int value) {
     if (strcmp(name, "tn_rounds") == 0) {
         WF3D_CHECK(value >= 1 && value <= 8, WF3D_ERR_ARG, "wf3d_set_option: tn_rounds must be 1..8 (got %d)", value);
         g_tn_rounds.store(value, std::memory_order_relaxed);
+        return WF3D_OK;
+    }
+    if (strcmp(name, "gemm_cus") == 0) {
+        WF3D_CHECK(value == 0 || (value >= 8 && value <= 1024), WF3D_ERR_ARG, "wf3d_set_option: gemm_cus must be 0 (all) or 8..1024 (got %d)", value);
+        g_gemm_cus.store(value, std::memory_order_relaxed);
         return WF3D_OK;
     }
     wf3d_set_error("wf3d_set_option: unknown option '%s'", name);
