@@ -211,6 +211,21 @@ def cpu_baseline(model, cfg, N, V, seconds_budget=25.0):
                       f"median {med * 1e3:.0f} ms/step, dropout 0"}
 
 
+def pmc_traffic(cfg):
+    """{"traffic": bytes beyond L2 per dominant-kernel launch, "traffic_profile": where it was measured} from the committed
+    rocprofv3 counter summary of this config (profiles/, scripts/summarize_profiles.py); None if there is none."""
+    name = f"{PROFILE_TAG}_pmc_summary.json" if cfg == "cfg2" else f"{PROFILE_TAG}_{cfg}_pmc_summary.json"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    try:
+        with open(path) as f:
+            d = json.load(f).get("cfg2" if cfg == "cfg2" else cfg) or {}
+        return {"traffic": d.get("gemm_hbm_bytes_per_launch"),
+                "traffic_profile": f"profiles/{name}: FETCH_SIZE x 2 + WRITE_SIZE per launch ({d.get('gemm_read_bytes_per_launch', 0) / 1e6:.0f} MB read + "
+                                   f"{d.get('gemm_write_bytes_per_launch', 0) / 1e6:.0f} MB written), separate --pmc passes of this bench"}
+    except (OSError, ValueError):
+        return {"traffic": None, "traffic_profile": f"profiles/{name} not found"}
+
+
 def power_probe(ops, device, seconds=1.2):
     """The dominant GEMM shape (131072 x 1024 -> 2048) in a loop under the board-power sensor, and the vendor library's
     plain bf16 GEMM of the same shape beside it: what the MFMA pipes deliver under this board's power cap."""
@@ -326,8 +341,9 @@ def main():
             peak, kern = FP32_MFMA_PEAK_TFLOPS, "gemm_kernel<2,2,2,2> (128x128x32 v_mfma_f32_32x32x2_f32)"
             extra = {}
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                # HBM-side bytes come from rocprofv3 PMC passes, not from this run: see the committed profile
-                "traffic": None, "traffic_profile": f"profiles/{PROFILE_TAG}_pmc_summary.json ({args.config})",
+                # HBM-side bytes come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, own runs), not from this run:
+                # the figure of the committed summary for this config, per launch like `achieved`
+                **pmc_traffic(args.config),
                 "kernel": kern, "launches_timed": g["launches"], "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
                 "gemm_ms_per_step": g["ms"] / ns, "steps_sampled": timer.steps_sampled,
                 "whole_step_tflops": total_fl * B * world * args.steps / dt / 1e12, **extra}
