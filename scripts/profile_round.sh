@@ -8,7 +8,7 @@ TAG=${1:?tag}; CFG=${2:-cfg2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 [ "$CFG" = cfg2 ] && T=$TAG || T=${TAG}_${CFG}
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --config $CFG --no-cpu-baseline"
+B="python3 $R/bench.py --config $CFG --no-cpu-baseline --no-power-probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${T}_trace2 -- $B --steps 3 --warmup 1 > $R/gpurun_out/prof_${T}_trace2.log 2>&1
 echo "trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${T}_fetch -- $B --steps 1 --warmup 1 > $R/gpurun_out/prof_${T}_fetch.log 2>&1

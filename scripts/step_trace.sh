@@ -4,7 +4,7 @@
 TAG=${1:?tag}; CFG=${2:-cfg2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/st_$TAG -- python3 $R/bench.py --config $CFG --no-cpu-baseline --steps 3 --warmup 2 > $R/gpurun_out/st_$TAG.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/st_$TAG -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-power-probe --steps 3 --warmup 2 > $R/gpurun_out/st_$TAG.log 2>&1
 python3 - "$R/gpurun_out/st_$TAG" > $R/gpurun_out/steptrace_$TAG.txt <<'PY'
 import csv, glob, sys
 d = sys.argv[1]

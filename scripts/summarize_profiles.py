@@ -35,8 +35,8 @@ os.makedirs(P, exist_ok=True)
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
-    return fs[-1] if fs else None
+    fs = glob.glob(os.path.join(G, pattern), recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None      # the latest run (process ids in the names do not sort by time)
 
 
 def short(n):
