@@ -278,3 +278,23 @@ def test_single_process_reducer_is_noop():
     g = m.vertex_predictor.weight.grad.clone()
     red.finish()
     assert torch.equal(g, m.vertex_predictor.weight.grad)
+
+
+def test_encoder_layers_leave_one_bucket_each_and_the_last_bucket_is_small():
+    """Bucket layout of the real model once every parameter is known to receive gradients: backward order, one bucket per
+    per-point-MLP layer, and the bucket that completes last (first two layers) is ~2 MB — the only reduce that cannot hide."""
+    import helpers as H  # noqa: F401  (sys.path)
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    from wf3d import dist as wd
+    m = PointCloudToWireframe(input_dim=8, max_vertices=64)
+    red = wd.GradReducer(m)
+    red._expected.update(p for p in m.parameters() if p.requires_grad)
+    red._build()
+    names = {p: n for n, p in m.named_parameters()}
+    firsts = [names[b["params"][0]] for b in red._buckets]
+    stages = [wd._stage_of(n) for n in firsts]
+    assert stages == sorted(stages)
+    enc = [[names[p] for p in b["params"]] for b in red._buckets if names[b["params"][0]].startswith("encoder.mlp.")]
+    assert [sorted({int(n.split(".")[2]) // 4 for n in ns}) for ns in enc] == [[4], [3], [2], [0, 1]]
+    assert red.bucket_summary()[-1][1] < 2.2 * 2 ** 20
+    assert sum(nb for _, nb in red.bucket_summary()) == 4 * sum(p.numel() for p in m.parameters() if p.requires_grad)

@@ -63,6 +63,15 @@ def _stage_of(name):
         return 1
     if name.startswith("encoder.feature_fusion."):
         return 2
+    # per-point MLP, last layer first.  Its gradients appear one layer at a time over the final 7 ms of the step, so each
+    # layer of `encoder.mlp` (Linear + LayerNorm: indices 4k .. 4k+3) is its own bucket and leaves as soon as it is complete;
+    # the two first layers (2 MB together) share the last one — what remains exposed after backward is that small reduce.
+    if name.startswith("encoder.mlp."):
+        try:
+            layer = int(name.split(".")[2]) // 4
+        except ValueError:
+            return 3
+        return 3 + (4 - max(layer, 1)) if layer <= 4 else 3      # reference depth: layers 0..4 -> stages 6, 6, 5, 4, 3
     return 3
 
 
