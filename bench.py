@@ -391,10 +391,17 @@ def main():
             res["dist_backend"] = torch.distributed.get_backend()
             res["allreduce_exposed_ms"] = ex[len(ex) // 2] if ex else None
             res["allreduce_buckets_mb"] = [round(nb / 2 ** 20, 1) for _, nb in reducer.bucket_summary()]
+        # the two side measurements must never cost the bench line itself
         if world == 1 and split and not args.no_power_probe:
-            roof["power"] = power_probe(ops, device)
+            try:
+                roof["power"] = power_probe(ops, device)
+            except Exception as e:  # noqa: BLE001
+                roof["power"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, args.config, N, V)
+            try:
+                res["cpu_baseline"] = cpu_baseline(model, args.config, N, V)
+            except Exception as e:  # noqa: BLE001
+                res["cpu_baseline"] = {"value": None, "unit": "clouds/s", "cores": host_cores(), "kind": "port", "sample": "failed: " + repr(e)[:300]}
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
