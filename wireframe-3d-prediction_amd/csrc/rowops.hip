@@ -172,9 +172,9 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
 #pragma unroll
                     for (int k = 0; k < 4; ++k) zn[i][k] = pa[i][k] + b[k] + xkn[0] * wdv[i][k];      // as pair_fwd_kernel formed it
                 } else {
-                    zn[i] = *reinterpret_cast<const f32x4*>(z + (size_t)row * D + c);
+                    zn[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + (size_t)row * D + c));     // last use of z
                 }
-                dn[i] = *reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c);
+                dn[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dh + (size_t)row * D + c));
             }
         }
         if (PAIR) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
 #pragma unroll
                     for (int k = 0; k < KX; ++k) a_dw[k][i] += o * xk[k];
                 }
-                if (dz) *reinterpret_cast<f32x4*>(dz + (size_t)row * D + c) = o;
+                if (dz) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dz + (size_t)row * D + c));
                 if (dz_sx8) {
                     // sx8 group = 8 columns = lanes (2m, 2m+1): even lane stores the 8 high parts,
                     // odd lane the 8 low parts, after swapping the halves they do not own
@@ -267,12 +267,15 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
                     const uint2 mine_hi = __builtin_bit_cast(uint2, hi), mine_lo = __builtin_bit_cast(uint2, lo);
                     const bool odd = lane & 1;
                     uint2 send = odd ? mine_hi : mine_lo, got;
-                    got.x = __shfl_xor((int)send.x, 1, 64);
-                    got.y = __shfl_xor((int)send.y, 1, 64);
+                    got.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+                    got.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
                     uint4 w = odd ? make_uint4(got.x, got.y, mine_lo.x, mine_lo.y)
                                   : make_uint4(mine_hi.x, mine_hi.y, got.x, got.y);
                     float* g = dz_sx8 + (size_t)row * D + (c & ~7) + (odd ? 4 : 0);
-                    *reinterpret_cast<uint4*>(g) = w;
+                    // streaming: non-temporal loads and stores together are worth 6-8 % on a copy of this shape
+                    // (scripts/micro/copy_patterns.hip)
+                    __builtin_nontemporal_store(f32x4{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)},
+                                                reinterpret_cast<f32x4*>(g));
                 }
             }
         }

@@ -25,6 +25,31 @@ __device__ __forceinline__ void store_sx8(float* dst, const float (&v)[8]) {
     *reinterpret_cast<f32x4*>(dst + 4) = __builtin_bit_cast(f32x4, lo);
 }
 
+// The same group written by a PAIR of lanes (lane-contiguous row passes): the even lane holds columns 0..3 of the group,
+// the odd lane columns 4..7, each at `dst` = the address of its own four fp32 columns.  After one exchange the even lane
+// owns the eight high parts (the group's first 16 bytes) and the odd lane the eight low parts (the second 16): every
+// lane writes 16 bytes right where it read 16 — consecutive lanes, consecutive bytes — instead of two stores 32 B apart.
+// (Measured on a plain copy of 131072 x 2048 floats, scripts/micro/copy_patterns.hip: 5.0 -> 5.4 TB/s for the store
+// pattern alone, 5.7 with non-temporal loads and stores, which the 32-B-apart stores cannot use: 3.9 TB/s.)
+__device__ __forceinline__ void store_sx8_pair(float* dst, const float (&v)[4], bool odd) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+    const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+    const unsigned s0 = odd ? H[0] : L[0], s1 = odd ? H[1] : L[1];
+    // neighbour exchange inside each quad: DPP quad_perm [1, 0, 3, 2] (a VALU move, no trip through the LDS crossbar)
+    const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);
+    const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+    const u32x4 o = odd ? u32x4{r0, r1, L[0], L[1]} : u32x4{H[0], H[1], r0, r1};
+    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, o), reinterpret_cast<f32x4*>(dst));
+}
+
 // out_sx8[r, c] = in[r*rs + c*cs]   (cs == 1: plain copy-convert; rs == 1: transpose)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ in, long rs, long cs, int R, int C,
                                                           float* __restrict__ out) {
@@ -122,21 +147,27 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
                                                        float* __restrict__ mu, float* __restrict__ rs,
                                                        float* __restrict__ h_sx8) {
     // persistent: a lane group walks rows first, first + step, ... with its slice of gamma / beta in registers and
-    // the next row's z already requested while this row is reduced, normalised and stored
-    constexpr int RPB = 256 / LPR;
+    // the next row's z already requested while this row is reduced, normalised and stored.
+    // Columns of a lane: two chunks of four per slot, CH columns apart — lane l owns [s*SPAN + 4l, +4) and
+    // [s*SPAN + CH + 4l, +4), so that every load and every store of the wave covers consecutive 16-byte pieces
+    // (SPAN = 8 * LPR columns per slot, CH = 4 * LPR).  Lanes 2m, 2m+1 share an sx8 group (store_sx8_pair).
+    constexpr int RPB = 256 / LPR, SPAN = 8 * LPR, CH = 4 * LPR;
     const int lane = threadIdx.x & (LPR - 1);
+    const bool odd = lane & 1;
     const int rstep = gridDim.x * RPB;
     float gm[NS][8], bt[NS][8];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int c = lane * 8 + 512 * i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { gm[i][j] = 1.f; bt[i][j] = 0.f; }
-        if (c < D) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { gm[i][j] = g0[j]; gm[i][4 + j] = g1[j]; bt[i][j] = b0[j]; bt[i][4 + j] = b1[j]; }
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c = SPAN * i + CH * hf + lane * 4;
+            if (c < D) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), b0 = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { gm[i][4 * hf + j] = g0[j]; bt[i][4 * hf + j] = b0[j]; }
+            }
         }
     }
     f32x4 na[NS], nb[NS];
@@ -144,9 +175,10 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
         const float* p = z + (size_t)min(row, R - 1) * D;          // clamped: a row >= R is loaded but never used
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int c = lane * 8 + 512 * i;
+            const int c = SPAN * i + lane * 4;
             na[i] = nb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < D) { na[i] = *reinterpret_cast<const f32x4*>(p + c); nb[i] = *reinterpret_cast<const f32x4*>(p + c + 4); }
+            if (c < D) na[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c));
+            if (c + CH < D) nb[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c + CH));
         }
     };
     int row = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -163,29 +195,31 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
         const float mean = row_sum<LPR>(s) / (float)D;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int c = lane * 8 + 512 * i;
-            if (c < D)
+        for (int i = 0; i < NS; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-        }
+            for (int hf = 0; hf < 2; ++hf)
+                if (SPAN * i + CH * hf + lane * 4 < D)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = v[i][4 * hf + j] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)D + eps);
         if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int c = lane * 8 + 512 * i;
-            if (c < D) {
-                float o[8];
+        for (int i = 0; i < NS; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = wf3d_act_rt(act, (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
-                if (thresh) {
+            for (int hf = 0; hf < 2; ++hf) {
+                const int c = SPAN * i + CH * hf + lane * 4;
+                if (c < D) {                       // D % 8 == 0: both lanes of a pair are in or out together
+                    float o[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        o[j] = wf3d_keep(seed, (uint32_t)row, (uint32_t)(c + j), thresh) ? o[j] * dscale : 0.f;
+                    for (int j = 0; j < 4; ++j) o[j] = wf3d_act_rt(act, (v[i][4 * hf + j] - mean) * rstd * gm[i][4 * hf + j] + bt[i][4 * hf + j]);
+                    if (thresh) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            o[j] = wf3d_keep(seed, (uint32_t)row, (uint32_t)(c + j), thresh) ? o[j] * dscale : 0.f;
+                    }
+                    store_sx8_pair(h_sx8 + (size_t)row * D + c, o, odd);
                 }
-                store_sx8(h_sx8 + (size_t)row * D + c, o);
             }
-        }
     }
 }
 
@@ -195,7 +229,8 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 // 2 KB-per-row WRITE (K <= 8: 8 FMAs per output), so instead of a GEMM that writes z and an
 // ln_prep pass that reads it back, one wave per row computes the row in registers from its
 // slice of W (kept in registers across rows), and writes z (kept for backward), (mu, rstd)
-// and h = act(LN(z)) in sx8.  Column layout per lane as in ln_prep_kernel.
+// and h = act(LN(z)) in sx8.  Column layout per lane as in ln_prep_kernel (lane-contiguous 16-B pieces, lane pairs
+// share an sx8 group; z and h leave through non-temporal stores).
 // FAST: K == 8, 16-byte aligned x rows and ReLU — two float4 loads per row, no per-element branches.
 template <int NS, bool FAST>
 __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restrict__ x, int ldx, int K,
@@ -206,17 +241,31 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
                                                            float* __restrict__ mu, float* __restrict__ rs,
                                                            float* __restrict__ h_sx8) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool odd = lane & 1;
+    // columns of a lane, slot i: [512 i + 4 lane, +4) (values 0..3) and [512 i + 256 + 4 lane, +4) (values 4..7)
+    auto col = [&](int i, int j) { return 512 * i + 256 * (j >> 2) + lane * 4 + (j & 3); };
     float w[NS][8][8], b[NS][8];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int c = lane * 8 + 512 * i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            b[i][j] = (c < D && bias) ? bias[c + j] : 0.f;
+            const int c = col(i, j);
+            b[i][j] = (c < D && bias) ? bias[c] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) w[i][j][k] = (c < D && k < K) ? W[(size_t)(c + j) * ldw + k] : 0.f;
+            for (int k = 0; k < 8; ++k) w[i][j][k] = (c < D && k < K) ? W[(size_t)c * ldw + k] : 0.f;
         }
     }
+    // gamma / beta stay in registers too: a load inside the row loop makes the compiler wait for EVERYTHING in flight
+    // (vmcnt(0): the row's own stores included) once per row
+    float gm[NS][8], bt[NS][8];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = col(i, j);
+            gm[i][j] = c < D ? gamma[c] : 1.f;
+            bt[i][j] = c < D ? beta[c] : 0.f;
+        }
     // the next row's x is requested before this row is computed and stored (one row ~ a memory round trip otherwise)
     auto load_x = [&](int row, float (&xr)[8]) {
         if (FAST) {
@@ -240,48 +289,44 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int c = lane * 8 + 512 * i;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a = fmaf(xr[k], w[i][j][k], a);
-                v[i][j] = c < D ? a + b[i][j] : 0.f;
+                v[i][j] = col(i, j) < D ? a + b[i][j] : 0.f;
                 s += v[i][j];
             }
-            if (c < D) {
-                float* zp = z + (size_t)row * D + c;
-                *reinterpret_cast<f32x4*>(zp) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
-                *reinterpret_cast<f32x4*>(zp + 4) = f32x4{v[i][4], v[i][5], v[i][6], v[i][7]};
-            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                if (col(i, 4 * hf) < D)
+                    __builtin_nontemporal_store(f32x4{v[i][4 * hf], v[i][4 * hf + 1], v[i][4 * hf + 2], v[i][4 * hf + 3]},
+                                                reinterpret_cast<f32x4*>(z + (size_t)row * D + col(i, 4 * hf)));
         }
         const float mean = wf3d_wave_sum(s) / (float)D;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int c = lane * 8 + 512 * i;
-            if (c < D)
+        for (int i = 0; i < NS; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-        }
+            for (int j = 0; j < 8; ++j)
+                if (col(i, j) < D) { const float d = v[i][j] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wf3d_wave_sum(q) / (float)D + eps);
         if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int c = lane * 8 + 512 * i;
-            if (c < D) {
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
-                float o[8];
+        for (int i = 0; i < NS; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y0 = (v[i][j] - mean) * rstd * g0[j] + b0[j], y1 = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
-                    o[j] = FAST ? fmaxf(y0, 0.f) : wf3d_act_rt(act, y0);
-                    o[4 + j] = FAST ? fmaxf(y1, 0.f) : wf3d_act_rt(act, y1);
+            for (int hf = 0; hf < 2; ++hf) {
+                const int c = col(i, 4 * hf);
+                if (c < D) {                       // D % 8 == 0: both lanes of a pair are in or out together
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float y0 = (v[i][4 * hf + j] - mean) * rstd * gm[i][4 * hf + j] + bt[i][4 * hf + j];
+                        o[j] = FAST ? fmaxf(y0, 0.f) : wf3d_act_rt(act, y0);
+                    }
+                    store_sx8_pair(h_sx8 + (size_t)row * D + c, o, odd);
                 }
-                store_sx8(h_sx8 + (size_t)row * D + c, o);
             }
-        }
     }
 }
 
