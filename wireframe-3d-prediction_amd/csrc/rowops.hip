@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
         edge_ij(r0 - ps.eoff[ps_s], ps_v, ps_i, ps_j);
     }
     auto load_row = [&](int it) {
-        const int row = row_of(it);
+        // the row index is the same for every lane of a wave: say so, and the per-row scalars (mu, rs, the K input values)
+        // come through the scalar cache in one or two s_load instead of 2 + K vector loads of one address each
+        const int row = __builtin_amdgcn_readfirstlane(row_of(it));
         const bool live = it < iters && row < R;
         mn = (has_ln && live) ? mu[row] : 0.f;
         rn = (has_ln && live) ? rs[row] : 1.f;
@@ -596,6 +598,7 @@ extern "C" int wf3d_ln_act_bwd_first(const float* dh, const float* z, const floa
 #define WF3D_BWD1(WPR_)                                                                                                  \
     hipLaunchKernelGGL((ln_act_bwd_kernel<1, WPR_, 8>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
                        act, 0u, 0u, 1.0f, (float*)nullptr, (float*)nullptr, part, x, ldx, K)
+    // (one wave per 512-wide row with two slots, <2, 1, 8>: 184 VGPRs, 187 us against 173)
     if (wpr == 4) WF3D_BWD1(4); else if (wpr == 2) WF3D_BWD1(2); else WF3D_BWD1(1);
 #undef WF3D_BWD1
     WF3D_LAUNCH_CHECK();
