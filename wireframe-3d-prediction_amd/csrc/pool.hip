@@ -192,9 +192,8 @@ __global__ __launch_bounds__(256) void pool4_final_kernel(const PoolPart* __rest
 // dpf written 16 B per lane: a thread owns 4 channels of one cloud (its 4 pooled cotangents and
 // 2 arg-max indices live in registers) and walks the points of its split; 256/(C/4) points of a
 // split are written per pass, each a contiguous C*4-byte row.
-// SX8: dpf is written as the next GEMMs' split operand (include/wf3d.h, sx8): of each group of 8 channels
-// the thread owning channels c..c+3 stores 4 bf16 high parts at byte (c & 7) * 2 of the group's first
-// 16 B and the 4 low parts at the same offset of its second 16 B.
+// SX8: dpf is written as the next GEMMs' split operand (include/wf3d.h, sx8): the two threads that own a group of 8
+// channels swap halves, one stores the group's 8 high parts, the other its 8 low parts (wf3d_store_sx8_pair).
 template <bool SX8>
 __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict__ valid, const float* __restrict__ cnt,
                                                          const int32_t* __restrict__ arg_m, const int32_t* __restrict__ arg_u,
@@ -230,15 +229,9 @@ __global__ __launch_bounds__(256) void pool4_bwd_kernel(const float* __restrict_
         }
         if (dpf_direct) g += *reinterpret_cast<const f32x4*>(dpf_direct + idx);
         if (SX8) {
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)g[j]; lo[j] = (__bf16)(g[j] - (float)hi[j]); }
-            float* grp = dpf + (idx & ~(size_t)7);
-            const int half = (c & 4) >> 1;                       // floats: 0 or 2 (= 8 bytes)
-            *reinterpret_cast<f32x2*>(grp + half) = __builtin_bit_cast(f32x2, hi);
-            *reinterpret_cast<f32x2*>(grp + 4 + half) = __builtin_bit_cast(f32x2, lo);
+            // lanes (2m, 2m+1) hold one sx8 group: one exchange, then 16 contiguous bytes per lane (wf3d_store_sx8_pair)
+            const float gv[4] = {g[0], g[1], g[2], g[3]};
+            wf3d_store_sx8_pair(dpf + idx, gv, (c & 4) != 0);
         } else {
             *reinterpret_cast<f32x4*>(dpf + idx) = g;
         }
