@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void pool4_partial_v4_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int nn = n + 16 * u;
-            if (nn < n1) { v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)nn * C); ok[u] = vp[nn]; }
+            if (nn < n1) { v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)nn * C)); ok[u] = vp[nn]; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
