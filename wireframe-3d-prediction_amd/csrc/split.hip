@@ -115,7 +115,8 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-template <int NS, int LPR = 64>
+// FULL: D == NS * 8 * LPR exactly — every column test folds away and the row loop is straight-line code
+template <int NS, int LPR = 64, bool FULL = false>
 __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ z, int R, int D,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int act, float eps, uint32_t seed, uint32_t thresh, float dscale,
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int c = SPAN * i + CH * hf + lane * 4;
-            if (c < D) {
+            if (FULL || c < D) {
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), b0 = *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { gm[i][4 * hf + j] = g0[j]; bt[i][4 * hf + j] = b0[j]; }
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
         for (int i = 0; i < NS; ++i) {
             const int c = SPAN * i + lane * 4;
             na[i] = nb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < D) na[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c));
-            if (c + CH < D) nb[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c + CH));
+            if (FULL || c < D) na[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c));
+            if (FULL || c + CH < D) nb[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c + CH));
         }
     };
     int row = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
         for (int i = 0; i < NS; ++i)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
-                if (SPAN * i + CH * hf + lane * 4 < D)
+                if (FULL || SPAN * i + CH * hf + lane * 4 < D)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const float d = v[i][4 * hf + j] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) / (float)D + eps);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int c = SPAN * i + CH * hf + lane * 4;
-                if (c < D) {                       // D % 8 == 0: both lanes of a pair are in or out together
+                if (FULL || c < D) {               // D % 8 == 0: both lanes of a pair are in or out together
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = wf3d_act_rt(act, (v[i][4 * hf + j] - mean) * rstd * gm[i][4 * hf + j] + bt[i][4 * hf + j]);
@@ -436,12 +437,16 @@ extern "C" int wf3d_ln_prep(const float* z, int R, int D, const float* gamma, co
     int blocks = wf3d_cdiv(R, rpb);
     if (blocks > lp_wgs) blocks = lp_wgs;
 #define WF3D_LP(NS_)                                                                                              \
-    hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(blocks), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
-                       drop_seed, thresh, dscale, mu, rs, (float*)h_sx8)
+    if (D == NS_ * 512)                                                                                           \
+        hipLaunchKernelGGL((ln_prep_kernel<NS_, 64, true>), dim3(blocks), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
+                           drop_seed, thresh, dscale, mu, rs, (float*)h_sx8);                                      \
+    else                                                                                                          \
+        hipLaunchKernelGGL((ln_prep_kernel<NS_>), dim3(blocks), dim3(256), 0, st, z, R, D, gamma, beta, act, eps, \
+                           drop_seed, thresh, dscale, mu, rs, (float*)h_sx8)
     if (D <= 256)      // two rows per wave
         hipLaunchKernelGGL((ln_prep_kernel<1, 32>), dim3(blocks), dim3(256), 0, st, z, R, D, gamma, beta, act, eps,
                            drop_seed, thresh, dscale, mu, rs, (float*)h_sx8);
-    else if (ns <= 1) WF3D_LP(1); else if (ns <= 2) WF3D_LP(2); else if (ns <= 4) WF3D_LP(4); else WF3D_LP(8);
+    else if (ns <= 1) { WF3D_LP(1); } else if (ns <= 2) { WF3D_LP(2); } else if (ns <= 4) { WF3D_LP(4); } else { WF3D_LP(8); }
 #undef WF3D_LP
     WF3D_LAUNCH_CHECK();
     return WF3D_OK;
