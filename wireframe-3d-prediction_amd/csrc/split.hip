@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ 
 // slice of W (kept in registers across rows), and writes z (kept for backward), (mu, rstd)
 // and h = act(LN(z)) in sx8.  Column layout per lane as in ln_prep_kernel (lane-contiguous 16-B pieces, lane pairs
 // share an sx8 group; z and h leave through non-temporal stores).
-// FAST: K == 8, 16-byte aligned x rows and ReLU — two float4 loads per row, no per-element branches.
+// FAST: K == 8, D a multiple of 512, 16-byte aligned x / W rows and ReLU — two float4 loads per row, no per-element branches.
 template <int NS, bool FAST>
 __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restrict__ x, int ldx, int K,
                                                            const float* __restrict__ W, int ldw,
@@ -220,28 +220,39 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
     const bool odd = lane & 1;
     // columns of a lane, slot i: [512 i + 4 lane, +4) (values 0..3) and [512 i + 256 + 4 lane, +4) (values 4..7)
     auto col = [&](int i, int j) { return 512 * i + 256 * (j >> 2) + lane * 4 + (j & 3); };
-    float w[NS][8][8], b[NS][8];
+    // W slice, bias, gamma, beta of the lane's columns stay in registers for all its rows (a load inside the row loop makes
+    // the compiler wait for EVERYTHING in flight, the row's own stores included, once per row).
+    // FAST also means D == 512 NS, K == 8 and 16-byte aligned W rows: the prologue is 16 + 6 vector loads, no tests.
+    float w[NS][8][8], b[NS][8], gm[NS][8], bt[NS][8];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
+        if (FAST) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = col(i, j);
-            b[i][j] = (c < D && bias) ? bias[c] : 0.f;
+            for (int hf = 0; hf < 2; ++hf) {
+                const int c = col(i, 4 * hf);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c), b4 = *reinterpret_cast<const f32x4*>(beta + c);
+                f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                if (bias) bb = *reinterpret_cast<const f32x4*>(bias + c);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) w[i][j][k] = (c < D && k < K) ? W[(size_t)c * ldw + k] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    gm[i][4 * hf + j] = g4[j]; bt[i][4 * hf + j] = b4[j]; b[i][4 * hf + j] = bb[j];
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + (size_t)(c + j) * ldw), w1 = *reinterpret_cast<const f32x4*>(W + (size_t)(c + j) * ldw + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { w[i][4 * hf + j][k] = w0[k]; w[i][4 * hf + j][4 + k] = w1[k]; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = col(i, j);
+                b[i][j] = (c < D && bias) ? bias[c] : 0.f;
+                gm[i][j] = c < D ? gamma[c] : 1.f;
+                bt[i][j] = c < D ? beta[c] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w[i][j][k] = (c < D && k < K) ? W[(size_t)c * ldw + k] : 0.f;
+            }
         }
     }
-    // gamma / beta stay in registers too: a load inside the row loop makes the compiler wait for EVERYTHING in flight
-    // (vmcnt(0): the row's own stores included) once per row
-    float gm[NS][8], bt[NS][8];
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = col(i, j);
-            gm[i][j] = c < D ? gamma[c] : 1.f;
-            bt[i][j] = c < D ? beta[c] : 0.f;
-        }
     // the next row's x is requested before this row is computed and stored (one row ~ a memory round trip otherwise)
     auto load_x = [&](int row, float (&xr)[8]) {
         if (FAST) {
@@ -270,12 +281,12 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
                 float a = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a = fmaf(xr[k], w[i][j][k], a);
-                v[i][j] = col(i, j) < D ? a + b[i][j] : 0.f;
+                v[i][j] = (FAST || col(i, j) < D) ? a + b[i][j] : 0.f;
                 s += v[i][j];
             }
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
-                if (col(i, 4 * hf) < D)
+                if (FAST || col(i, 4 * hf) < D)
                     __builtin_nontemporal_store(f32x4{v[i][4 * hf], v[i][4 * hf + 1], v[i][4 * hf + 2], v[i][4 * hf + 3]},
                                                 reinterpret_cast<f32x4*>(z + (size_t)row * D + col(i, 4 * hf)));
         }
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
         for (int i = 0; i < NS; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (col(i, j) < D) { const float d = v[i][j] - mean; q += d * d; }
+                if (FAST || col(i, j) < D) { const float d = v[i][j] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(wf3d_wave_sum(q) / (float)D + eps);
         if (lane == 0) { mu[row] = mean; rs[row] = rstd; }
 #pragma unroll
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* __restric
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int c = col(i, 4 * hf);
-                if (c < D) {                       // D % 8 == 0: both lanes of a pair are in or out together
+                if (FAST || c < D) {               // D % 8 == 0: both lanes of a pair are in or out together
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -463,12 +474,15 @@ extern "C" int wf3d_first_layer_fwd(const float* x, int R, int K, int ldx, const
     WF3D_CHECK(x && W && gamma && beta && z && mu && rs && h_sx8, WF3D_ERR_ARG, "wf3d_first_layer_fwd: null pointer");
     WF3D_CHECK(((uintptr_t)z % 16 == 0) && ((uintptr_t)h_sx8 % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
                ((uintptr_t)beta % 16 == 0), WF3D_ERR_ARG, "wf3d_first_layer_fwd: pointers must be 16-byte aligned");
-    // persistent: two workgroups per CU (512 measured best of 512..8192), each wave keeps its slice of W in registers for all its rows
-    static const int fl_blocks = [] { const char* e = getenv("WF3D_FL_BLOCKS"); return e ? atoi(e) : 512; }();
+    // each wave keeps its slice of W in registers for all its rows; 4096 workgroups measured best of 512..32768 with the
+    // vector prologue (118 / 124 / 112 / 106 / 129 us at 512 / 1024 / 2048 / 4096 / 8192; 512 was best while the prologue
+    // was 72 single loads)
+    static const int fl_blocks = [] { const char* e = getenv("WF3D_FL_BLOCKS"); return e ? atoi(e) : 4096; }();
     int blocks = wf3d_cdiv(R, 4);
     blocks = blocks > fl_blocks ? fl_blocks : (blocks < 1 ? 1 : blocks);
     hipStream_t st = (hipStream_t)stream;
-    const bool fast = K == 8 && ldx % 4 == 0 && ((uintptr_t)x % 16 == 0) && act == WF3D_ACT_RELU;
+    const bool fast = K == 8 && ldx % 4 == 0 && ((uintptr_t)x % 16 == 0) && act == WF3D_ACT_RELU && D % 512 == 0 && ldw % 4 == 0 &&
+                      ((uintptr_t)W % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0);
 #define WF3D_FL(NS_, F_)                                                                                               \
     hipLaunchKernelGGL((first_layer_kernel<NS_, F_>), dim3(blocks), dim3(256), 0, st, x, ldx, K, W, ldw, bias, R, D, gamma, \
                        beta, act, eps, z, mu, rs, (float*)h_sx8)
