@@ -27,7 +27,7 @@ with torch.no_grad():
     for n, p in model.named_parameters():
         if p.dim() == 1:
             p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))).to(dev))
-for seed in range(100, 132):
+for seed in range(int(os.environ.get("SEED0", "100")), int(os.environ.get("SEED0", "100")) + 32):
     x, cnt, gen, _ = T._case(seed, B, N, V, counts)
     model.zero_grad(set_to_none=True)
     out = model(x.to(dev), cnt.to(dev))

