@@ -174,7 +174,7 @@ def test_dropout_mask_consistency(ops):
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("R,D", [(37, 32), (300, 512), (64, 2048), (5, 4096), (1025, 1024), (3, 16)])
+@pytest.mark.parametrize("R,D", [(37, 32), (300, 512), (64, 2048), (5, 4096), (1025, 1024), (3, 16), (9, 264), (11, 516), (7, 1032), (5, 4088)])
 def test_ln_act_bwd(ops, act, R, D):
     Z = rnd(R, D, seed=1, scale=1.5) + 0.2
     gamma, beta = 1 + 0.2 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
@@ -333,7 +333,9 @@ def test_gemm_split_long_k_splitk(ops):
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("R,D", [(37, 32), (300, 512), (129, 2048), (5, 4096)])
+@pytest.mark.parametrize("R,D", [(37, 32), (300, 512), (129, 2048), (5, 4096),
+                                 # widths that leave slots partly empty / exactly full, both lane groupings, odd row counts
+                                 (1, 8), (3, 136), (77, 256), (9, 264), (131, 768), (64, 1024), (5, 1032), (33, 1536)])
 def test_ln_prep_and_bwd_split_output(ops, act, R, D):
     Z = rnd(R, D, seed=1, scale=1.5) + 0.2
     gamma, beta = 1 + 0.2 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
@@ -419,7 +421,7 @@ def test_gemm_split_tn_matches_transposed_nt_path(ops, K, Mo, No):
     assert not ops.gemm_split_tn_ok(ops.split_rows(rnd(64, 136, seed=3)), Bs[:64])
 
 
-@pytest.mark.parametrize("R,K,D", [(1000, 8, 512), (37, 3, 64), (4096, 8, 1024), (5, 8, 8)])
+@pytest.mark.parametrize("R,K,D", [(1000, 8, 512), (37, 3, 64), (4096, 8, 1024), (5, 8, 8), (33, 8, 520), (7, 5, 264), (19999, 8, 512)])
 def test_first_layer_fused_forward_and_backward(ops, R, K, D):
     """Layer 0 of the per-point MLP: fused Linear+LN+ReLU+split forward == GEMM then ln_prep; fused backward
     (LN/ReLU backward + bias + weight gradient, no dz) == ln_act_bwd + TN GEMM."""

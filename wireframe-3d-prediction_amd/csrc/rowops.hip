@@ -87,6 +87,14 @@ __global__ __launch_bounds__(256) void ln_act_apply_kernel(const float* __restri
 // z[e, :] = Pa[i, :] + Pb[j, :] + |c_i - c_j| * w_dist — the expression pair_fwd_kernel evaluated — from the two per-vertex
 // tables (V x H per sample: L2-resident) and the row's (i, j), so that `pre` (2 KB per edge row: 2.1 GB at
 // max_vertices = 256) need not be written by the forward pass nor read here.
+// Columns per wave slice when WPR waves share a row: whole sx8 groups (multiples of 8) whenever the row is made of them —
+// the two lanes that exchange halves of a group (even lane: columns 0..3, odd lane: 4..7) must sit in the same slice with
+// the even lane first; a slice starting at a column = 4 (mod 8) paired every lane with the wrong neighbour and the sx8
+// copy of dz was garbage for such widths (D = 264 with two waves per row: found by a round-3 test, no model width hits it).
+__host__ __device__ __forceinline__ int slice_cols(int D, int wpr) {
+    return D % 8 == 0 ? (D / 8 + wpr - 1) / wpr * 8 : (D / 4 + wpr - 1) / wpr * 4;
+}
+
 struct PairSrc {
     const float* Pa; const float* Pb; const float* wd; int wd_stride;
     const int32_t* voff; const int32_t* eoff; const int32_t* esample;
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict
     __shared__ float xsum[2][4][2];                    // [parity][wave][s1, s2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wslice = wave % WPR, wrow = wave / WPR;
-    const int Dw = (D / 4 + WPR - 1) / WPR * 4;        // columns per wave slice (multiple of 4)
+    const int Dw = slice_cols(D, WPR);                 // columns per wave slice
     const int cbeg = wslice * Dw, cend = min(D, cbeg + Dw);
     const bool has_ln = mu != nullptr;
     f32x4 gam[NS], bet[NS];
@@ -548,7 +556,7 @@ extern "C" int wf3d_ln_act_bwd(const float* dh, const float* z, int R, int D, co
     const size_t lds = (size_t)3 * D * sizeof(float);
     // waves per row: keep <= 2 float4 slots per lane (NS) wherever possible
     const int wpr = D > 512 ? 4 : (D > 256 ? 2 : 1);
-    const int ns = wf3d_cdiv(wf3d_cdiv(D / 4, wpr) * 4, 256);
+    const int ns = wf3d_cdiv(slice_cols(D, wpr), 256);
 #define WF3D_BWD(NS_, WPR_)                                                                                       \
     hipLaunchKernelGGL((ln_act_bwd_kernel<NS_, WPR_>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, \
                        beta, act, drop_seed, thresh, scale, dz, (float*)dz_sx8, part)
@@ -636,7 +644,7 @@ extern "C" int wf3d_ln_act_bwd_wsum(const float* dh, const float* z, const float
     float* part = (float*)ws;
     const size_t lds = (size_t)4 * D * sizeof(float);
     const int wpr = D > 512 ? 4 : (D > 256 ? 2 : 1);
-    const int ns = wf3d_cdiv(wf3d_cdiv(D / 4, wpr) * 4, 256);
+    const int ns = wf3d_cdiv(slice_cols(D, wpr), 256);
 #define WF3D_BWDW(NS_, WPR_)                                                                                             \
     hipLaunchKernelGGL((ln_act_bwd_kernel<NS_, WPR_, 1>), dim3(nblk), dim3(256), lds, st, dh, z, R, D, mu, rs, gamma, beta, \
                        act, drop_seed, thresh, scale, dz, (float*)dz_sx8, part, wrow, 1, 1)
