@@ -209,7 +209,7 @@ def test_colsum(ops, R, D):
     assert rel(ops.colsum(X, w, ops.ACT_GELU), want) < TOL_ELT
 
 
-@pytest.mark.parametrize("B,N,C", [(3, 37, 16), (2, 1000, 512), (1, 4096, 512), (5, 33, 300)])
+@pytest.mark.parametrize("B,N,C", [(3, 37, 16), (2, 1000, 512), (1, 4096, 512), (5, 33, 300), (2, 19, 8), (2, 50, 24), (1, 23, 1032), (2, 12, 2048), (2, 31, 768), (3, 13, 40)])
 def test_pool4_fwd_bwd(ops, B, N, C):
     x = rnd(B, N, 8, seed=1)
     x[:, ::7] = 0.0                       # zero-padded points

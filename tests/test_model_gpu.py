@@ -579,3 +579,49 @@ def test_input_cloud_gradient_matches_oracle(precision):
     sum((ref[k] * cot[k].double()).sum() for k in cot).backward()
     e = H.elem_err(xd.grad.cpu().numpy(), x64.grad.numpy())
     assert e < (1e-4 if precision == "fp32" else 2e-4), e
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("hidden,out", [([256, 768], 768), ([512], 96), ([264, 520], 264), ([1024, 1536], 1280)])
+def test_encoder_other_widths_vs_oracle(precision, hidden, out):
+    """PointNetEncoder is general in hidden_dims / output_dim (reference models/PointNetEncoder.py:19-47): widths that are
+    not the model's — slots of the row passes partly filled, channel counts whose quarter does not divide 256, layer
+    widths the persistent GEMM does not tile — against the fp64 oracle, rows enough for the split path (3,072)."""
+    from models.PointNetEncoder import PointNetEncoder
+    from wf3d import config
+    old = config.precision()
+    config.set_precision(precision)
+    try:
+        torch.manual_seed(5)
+        enc = PointNetEncoder(8, hidden, out).to(dev())
+        with torch.no_grad():
+            for n, p in enc.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
+        g0 = torch.Generator().manual_seed(9)
+        x = torch.randn(3, 1024, 8, generator=g0)
+        x[:, ::9] = 0.0
+        cg, cp = torch.randn(3, out, generator=g0), torch.randn(3, 1024, out, generator=g0) * 0.01
+        g, pf = enc(x.to(dev()))
+        ((g * cg.to(dev())).sum() + (pf * cp.to(dev())).sum()).backward()
+        P = oracle.params_from_module(enc, dtype=torch.float64)
+        P = {"encoder." + k: v for k, v in P.items()}
+        rg, rpf = oracle.encoder_forward(P, x.double())
+        ((rg * cg.double()).sum() + (rpf * cp.double()).sum()).backward()
+        assert H.rel_err(g.detach().cpu().numpy(), rg.detach().numpy()) < TOL_OUT
+        assert H.rel_err(pf.detach().cpu().numpy(), rpf.detach().numpy()) < TOL_OUT
+        for n, p in enc.named_parameters():
+            ref = P["encoder." + n].grad
+            assert ref is not None and p.grad is not None, n
+            # not decision-frozen: ReLU decisions at |y| below the arithmetic's forward error differ from fp64's (fp32: under
+            # one element per layer here; bf16x3: dozens), and a flipped element on a row that is some channel's arg-max
+            # carries that channel's whole pooled cotangent.  So: every element for fp32 (measured 6e-3 at worst), the L2
+            # norm for bf16x3 (a lane pair writing the wrong 8 of 520 columns would be 0.12).
+            a, b = p.grad.double().cpu(), ref
+            if precision == "fp32":
+                assert H.rel_err(a.numpy(), b.numpy()) < 2e-2, (n, H.rel_err(a.numpy(), b.numpy()))
+            else:
+                l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                assert l2 < 3e-2, (n, l2)
+    finally:
+        config.set_precision(old)

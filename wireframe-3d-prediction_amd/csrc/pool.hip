@@ -387,8 +387,9 @@ static int pool4_bwd_impl(const float* valid, const float* cnt, const int32_t* a
     WF3D_CHECK(valid && cnt && arg_m && arg_u && dpf, WF3D_ERR_ARG, "wf3d_pool4_bwd: null pointer");
     const auto al = [](const float* p, int ld) { return !p || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
     const bool vec = C % 4 == 0 && ((uintptr_t)dpf % 16 == 0) && (!dpf_direct || (uintptr_t)dpf_direct % 16 == 0) &&
-                     al(dmmax, ldm) && al(dmavg, ldm) && al(dumean, ldu) && al(dumax, ldu) &&
-                     (C / 4 >= 256 || 256 % (C / 4) == 0);
+                     al(dmmax, ldm) && al(dmavg, ldm) && al(dumean, ldu) && al(dumax, ldu);
+    // (any C / 4: the kernel idles the threads beyond rows-per-pass x C / 4 of a workgroup — PointNetEncoder(output_dim=768)
+    // used to be refused here, in the middle of a backward pass)
     WF3D_CHECK(!sx8 || (vec && C % 8 == 0), WF3D_ERR_UNSUPPORTED, "wf3d_pool4_bwd_sx8: needs C %% 8 == 0 and 16-B aligned tensors (C=%d)", C);
     if (vec) {
         int ns = 4096 / (B * wf3d_cdiv(C / 4, 256));
