@@ -85,14 +85,11 @@ def test_small_edge_vs_golden(V, precision):
             assert p.grad is None, n            # spatial_proj is never used
 
 
-@pytest.mark.parametrize("vd", [2, 4, 6])
-def test_edge_head_other_vertex_dims_vs_oracle(vd, precision):
-    """EdgePredictor(vertex_dim != 3) (reference models/EdgePredictor.py:19-31 is general in it; PointCloudToWireframe
-    uses 3): forward and every gradient against the fp64 oracle on a ragged pair of samples.  vd <= 4 takes the
-    coordinate columns as a low-rank GEMM epilogue, vd = 6 as a separate accumulate."""
+def _edge_head_case(vd, hidden, heads, counts, precision, seed):
+    """EdgePredictor(vd, hidden, heads) on a ragged batch: forward and every gradient element against the fp64 oracle."""
     from models.EdgePredictor import EdgePredictor
-    torch.manual_seed(40 + vd)
-    ep = EdgePredictor(vd, 64, 2).to(dev())
+    torch.manual_seed(seed)
+    ep = EdgePredictor(vd, hidden, heads).to(dev())
     for sub in ep.modules():
         if isinstance(sub, torch.nn.Dropout):
             sub.p = 0.0
@@ -103,8 +100,8 @@ def test_edge_head_other_vertex_dims_vs_oracle(vd, precision):
             if p_.dim() == 1:
                 p_.add_(0.05 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
     g = torch.Generator().manual_seed(7)
-    counts = [7, 4]
-    v = torch.randn(2, 7, vd, generator=g)
+    vmax = max(counts)
+    v = torch.randn(len(counts), vmax, vd, generator=g)
     vg = v.clone().to(dev()).requires_grad_()
     probs = ep.forward_ragged(vg, counts)
     cot = torch.randn(probs.shape, generator=g)
@@ -113,7 +110,7 @@ def test_edge_head_other_vertex_dims_vs_oracle(vd, precision):
     vr = v.double().requires_grad_()
     tot = 0.0
     for s_, c in enumerate(counts):
-        pr, _ = oracle.edge_forward(P, vr[s_:s_ + 1, :c], num_heads=2)
+        pr, _ = oracle.edge_forward(P, vr[s_:s_ + 1, :c], num_heads=heads)
         assert H.elem_err(probs[s_, :pr.shape[1]].detach().cpu().numpy(), pr[0].detach().numpy(), 1e-6) < TOL_OUT
         if pr.shape[1] < probs.shape[1]:
             assert float(probs[s_, pr.shape[1]:].abs().max()) == 0.0          # padding exactly 0
@@ -126,9 +123,27 @@ def test_edge_head_other_vertex_dims_vs_oracle(vd, precision):
         if ref is None:
             assert p_.grad is None, n
         else:
-            assert H.elem_err(p_.grad.cpu().numpy(), ref.numpy()) < tol, n
+            assert H.elem_err(p_.grad.cpu().numpy(), ref.numpy()) < tol, (n, H.elem_err(p_.grad.cpu().numpy(), ref.numpy()))
+
+
+@pytest.mark.parametrize("vd", [2, 4, 6])
+def test_edge_head_other_vertex_dims_vs_oracle(vd, precision):
+    """EdgePredictor(vertex_dim != 3) (reference models/EdgePredictor.py:19-31 is general in it; PointCloudToWireframe
+    uses 3): forward and every gradient against the fp64 oracle on a ragged pair of samples.  vd <= 4 takes the
+    coordinate columns as a low-rank GEMM epilogue, vd = 6 as a separate accumulate."""
+    from models.EdgePredictor import EdgePredictor
+    _edge_head_case(vd, 64, 2, [7, 4], precision, 40 + vd)
     with pytest.raises(ValueError):
         EdgePredictor(9, 64, 2)
+
+
+@pytest.mark.parametrize("hidden,heads,counts", [(128, 8, [9, 3]), (256, 4, [12, 2, 7]), (384, 6, [5, 5]), (96, 3, [8, 6]),
+                                                 (208, 4, [6, 4]), (256, 4, [50, 3]), (1024, 16, [6, 3])])
+def test_edge_head_other_hidden_sizes_vs_oracle(hidden, heads, counts, precision):
+    """EdgePredictor(hidden_dim, num_heads) other than (512, 8) (reference models/EdgePredictor.py:19): head widths 16 / 32 /
+    52 on the VALU attention kernels, 64 on the MFMA ones, pair / LayerNorm kernels at row widths 96 ... 1024, and
+    (256, 4, [50, 3]): 1,228 edge rows, enough for the split GEMMs of the edge MLP in bf16x3 mode."""
+    _edge_head_case(3, hidden, heads, counts, precision, 60 + hidden)
 
 
 @pytest.mark.parametrize("V", [0, 1])

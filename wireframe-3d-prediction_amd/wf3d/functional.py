@@ -495,7 +495,9 @@ class EdgeFn(torch.autograd.Function):
             Pb = ops.gemm(Fm, Wb, NT, x3=x3)
             ops.gemm(cv, Wd, NT, out=Pb, accumulate=True)
         # the two wide edge-MLP layers (E rows: 52 % of the FLOPs at V=256) on the split path
-        split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True)
+        # (H / 4, the third layer's width, is the reduction width of its dgrad and the row length of its transposed weight:
+        # it has to be made of whole 8-column groups too — EdgePredictor(hidden_dim=208) used to fail in split_weights)
+        split = _split_ok(meta.Re, H, precision == "bf16x3") and _split_ok(meta.Re, H // 2, True) and (H // 4) % 8 == 0
         if split:
             # the pair kernel holds each edge row in registers: it also emits gelu(LN(pre)) as the next GEMM's operand.
             # `pre` itself (2 KB per edge row) is stored only when something in backward reads it: with the wgrad of the
