@@ -640,3 +640,38 @@ def test_encoder_other_widths_vs_oracle(precision, hidden, out):
                 assert l2 < 3e-2, (n, l2)
     finally:
         config.set_precision(old)
+
+
+@pytest.mark.parametrize("gdim,V,B,npts", [(384, 10, 5, 17), (512, 100, 3, 9), (200, 7, 33, 12), (520, 3, 2, 33), (64, 40, 32, 5), (1024, 12, 4, 8)])
+def test_vertex_head_other_sizes_vs_oracle(gdim, V, B, npts):
+    """VertexPredictor(global_feature_dim, max_vertices) other than (512, 64) (reference models/VertexPredictor.py:19):
+    input widths that are not multiples of 512, the skinny kernels (B <= 32) and the generic GEMM path (B = 33),
+    against the fp64 oracle — outputs and every gradient, relative to each tensor's scale."""
+    from models.VertexPredictor import VertexPredictor
+    torch.manual_seed(gdim + V)
+    vp = VertexPredictor(gdim, V, 4).to(dev())
+    vp.ensure_point_pool_proj(2 * gdim, dev())
+    with torch.no_grad():
+        for n, p in vp.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))).to(dev()))
+    g0 = torch.Generator().manual_seed(3)
+    g = torch.randn(B, gdim, generator=g0)
+    pf = torch.randn(B, npts, gdim, generator=g0)
+    gg, pg = g.clone().to(dev()).requires_grad_(), pf.clone().to(dev()).requires_grad_()
+    out = vp(gg, pg)
+    cv, ce = torch.randn(B, V, 3, generator=g0), torch.randn(B, V, generator=g0)
+    ((out["vertices"] * cv.to(dev())).sum() + (out["existence_probabilities"] * ce.to(dev())).sum()).backward()
+    P = {"vertex_predictor." + n: p.detach().cpu().double().requires_grad_() for n, p in vp.named_parameters()}
+    gr, pr = g.double().requires_grad_(), pf.double().requires_grad_()
+    ref = oracle.vertex_forward(P, gr, pr, V, 4)
+    ((ref["vertices"] * cv.double()).sum() + (ref["existence_probabilities"] * ce.double()).sum()).backward()
+    assert H.rel_err(out["vertices"].detach().cpu().numpy(), ref["vertices"].detach().numpy()) < TOL_OUT
+    assert H.rel_err(out["existence_probabilities"].detach().cpu().numpy(), ref["existence_probabilities"].detach().numpy()) < TOL_OUT
+    assert np.array_equal(out["actual_vertex_counts"].cpu().numpy(), ref["actual_vertex_counts"].numpy())
+    assert H.rel_err(gg.grad.cpu().numpy(), gr.grad.numpy()) < TOL_GRAD
+    assert H.rel_err(pg.grad.cpu().numpy(), pr.grad.numpy()) < TOL_GRAD
+    for n, p in vp.named_parameters():
+        r = P["vertex_predictor." + n].grad
+        assert r is not None and p.grad is not None, n
+        assert H.rel_err(p.grad.cpu().numpy(), r.numpy()) < TOL_GRAD, (n, H.rel_err(p.grad.cpu().numpy(), r.numpy()))
