@@ -178,3 +178,17 @@ def test_frozen_gradients_production_kernel_selection():
     assert len(errs) == 76
     bad = [(n, e) for n, e in errs.items() if not e <= TOL_X3]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,N,V,counts", [(5, 1000, 9, [9, 2, 5, 7, 3]), (3, 1371, 12, [12, 4, 9]), (2, 2600, 6, [6, 6])])
+def test_frozen_gradients_ragged_row_counts_default_selection(B, N, V, counts, precision="bf16x3"):
+    """Default kernel selection at row counts the tiled kernels do not divide: M = 5,000 / 4,113 / 5,200 rows (not multiples
+    of 256, 4,113 not even of 8) — partial tiles in the split GEMMs, reductions the transposing wgrad kernel refuses (it then
+    goes through materialised transposes or the fp32 TN GEMM), ragged last workgroups of the row passes.  bf16x3 only: with
+    millions of activations some always lie within 5e-7 of 0, and only the split path's own operands give exact masks."""
+    fwd, errs, seed = _run(precision, B, N, V, counts, min_rows=None, kernel_masks=True, draws=16)
+    for k, (a, b) in fwd.items():
+        assert a < TOL and b < TOL, (k, a, b)
+    tol = TOL if precision == "fp32" else TOL_X3
+    bad = [(n, e) for n, e in errs.items() if not e <= tol]
+    assert not bad, (seed, sorted(bad, key=lambda t: -t[1])[:5])

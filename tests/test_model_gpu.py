@@ -597,7 +597,7 @@ def test_input_cloud_gradient_matches_oracle(precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("hidden,out", [([256, 768], 768), ([512], 96), ([264, 520], 264), ([1024, 1536], 1280)])
+@pytest.mark.parametrize("hidden,out", [([256, 768], 768), ([512], 96), ([264, 520], 264), ([1024, 1536], 1280), ([64, 128, 256, 128, 64], 32), ([], 40)])
 def test_encoder_other_widths_vs_oracle(precision, hidden, out):
     """PointNetEncoder is general in hidden_dims / output_dim (reference models/PointNetEncoder.py:19-47): widths that are
     not the model's — slots of the row passes partly filled, channel counts whose quarter does not divide 256, layer
