@@ -675,3 +675,25 @@ def test_vertex_head_other_sizes_vs_oracle(gdim, V, B, npts):
         r = P["vertex_predictor." + n].grad
         assert r is not None and p.grad is not None, n
         assert H.rel_err(p.grad.cpu().numpy(), r.numpy()) < TOL_GRAD, (n, H.rel_err(p.grad.cpu().numpy(), r.numpy()))
+
+
+def test_input_layouts_and_dtypes_give_the_same_result():
+    """Strided / non-fp32 point clouds and count tensors in other integer types and devices are accepted and mean the same
+    thing (the reference's modules take whatever torch ops take)."""
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    torch.manual_seed(11)
+    m = PointCloudToWireframe(8, 6).to(dev())
+    m.vertex_predictor.ensure_point_pool_proj(1024, dev())
+    m.set_dropout(0.0)
+    m.train()
+    g = torch.Generator().manual_seed(2)
+    big = torch.randn(3, 2 * 300, 8, generator=g).to(dev())
+    x = big[:, ::2, :]                                       # strided view
+    counts = torch.tensor([6, 2, 4])
+    for xv, cv in ((x, counts.to(dev())), (x.double(), counts), (x.contiguous().half(), counts.int().to(dev())),
+                   (x.permute(1, 0, 2).contiguous().permute(1, 0, 2), counts.to(dev()).to(torch.int16))):
+        out = m(xv, cv)
+        ref = m(xv.float().contiguous(), counts.to(dev()))       # the same values as a plain fp32 tensor and int64 counts
+        for k in ("vertices", "existence_probabilities", "edge_probs", "global_features"):
+            assert torch.equal(out[k], ref[k]), k
+        assert out["edge_indices"] == ref["edge_indices"]
