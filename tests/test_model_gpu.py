@@ -697,3 +697,17 @@ def test_input_layouts_and_dtypes_give_the_same_result():
         for k in ("vertices", "existence_probabilities", "edge_probs", "global_features"):
             assert torch.equal(out[k], ref[k]), k
         assert out["edge_indices"] == ref["edge_indices"]
+
+
+def test_count_tensor_shorter_or_longer_than_the_batch():
+    """The reference reads target_vertex_counts[i] for i < batch: too few entries is its IndexError, extra ones are ignored."""
+    from models.PointCloudToWireframe import PointCloudToWireframe
+    torch.manual_seed(12)
+    m = PointCloudToWireframe(8, 6).to(dev())
+    m.set_dropout(0.0)
+    m.train()
+    x = torch.randn(2, 64, 8, device=dev())
+    with pytest.raises(IndexError, match="out of bounds"):
+        m(x, torch.tensor([5], device=dev()))
+    a, b = m(x, torch.tensor([5, 3, 6, 2], device=dev())), m(x, torch.tensor([5, 3], device=dev()))
+    assert torch.equal(a["edge_probs"], b["edge_probs"]) and a["edge_indices"] == b["edge_indices"]

@@ -55,6 +55,11 @@ class PointCloudToWireframe(nn.Module):
             counts = self._host_counts(target_vertex_counts)          # ground-truth counts (:77-86)
         else:
             counts = [int(c) for c in vo["actual_vertex_counts"].tolist()]   # data-dependent (:87-97)
+        b = verts.shape[0]
+        if len(counts) < b:
+            # the reference reads target_vertex_counts[i] for every sample i of the batch (:78-80)
+            raise IndexError(f"index {len(counts)} is out of bounds for dimension 0 with size {len(counts)}")
+        counts = counts[:b]                                                   # entries beyond the batch are never read there
         v = self.max_vertices
         counts = [min(c, v) if c >= 0 else max(v + c, 0) for c in counts]    # what `[:count]` slicing does
         probs = self.edge_predictor.forward_ragged(verts, counts)
