@@ -711,3 +711,14 @@ def test_count_tensor_shorter_or_longer_than_the_batch():
         m(x, torch.tensor([5], device=dev()))
     a, b = m(x, torch.tensor([5, 3, 6, 2], device=dev())), m(x, torch.tensor([5, 3], device=dev()))
     assert torch.equal(a["edge_probs"], b["edge_probs"]) and a["edge_indices"] == b["edge_indices"]
+
+
+def test_forward_ragged_counts_beyond_the_padded_width_are_cut():
+    from models.EdgePredictor import EdgePredictor
+    torch.manual_seed(13)
+    ep = EdgePredictor(3, 64, 2).to(dev()).eval()
+    v = torch.randn(2, 5, 3, device=dev())
+    a, b = ep.forward_ragged(v, [9, 3]), ep.forward_ragged(v, [5, 3])
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="counts for a batch"):
+        ep.forward_ragged(v, [5])

@@ -55,7 +55,9 @@ class EdgePredictor(nn.Module):
     def forward_ragged(self, vertices, counts):
         """vertices [B, Vmax, 3]; sample s uses its first counts[s] vertices.
         Returns zero-padded probabilities [B, max_s E_s]."""
-        counts = [int(c) for c in counts]
+        if len(counts) != vertices.shape[0]:
+            raise ValueError(f"forward_ragged: {len(counts)} counts for a batch of {vertices.shape[0]}")
+        counts = [min(int(c), vertices.shape[1]) for c in counts]      # `vertices[i, :count]` cannot take more than there is
         if any(c < 2 for c in counts):
             # the reference indexes a 1-D empty index tensor here (EdgePredictor.py:118)
             raise IndexError("too many indices for tensor of dimension 1")
