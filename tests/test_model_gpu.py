@@ -722,3 +722,10 @@ def test_forward_ragged_counts_beyond_the_padded_width_are_cut():
     assert torch.equal(a, b)
     with pytest.raises(ValueError, match="counts for a batch"):
         ep.forward_ragged(v, [5])
+
+
+@pytest.mark.parametrize("hidden,heads", [(120, 5), (72, 3), (8, 1), (520, 8), (100, 4), (64, 3)])
+def test_edge_head_sizes_outside_the_kernels_granularity_are_refused_at_construction(hidden, heads):
+    from models.EdgePredictor import EdgePredictor
+    with pytest.raises(ValueError, match="hidden_dim"):
+        EdgePredictor(3, hidden, heads)

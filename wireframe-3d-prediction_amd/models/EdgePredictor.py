@@ -18,6 +18,11 @@ class EdgePredictor(nn.Module):
         super().__init__()
         if not 1 <= vertex_dim <= 8:
             raise ValueError("the HIP edge head takes 1..8 coordinates per vertex (reference default: 3)")
+        if hidden_dim % 16 or hidden_dim % num_heads or (hidden_dim // num_heads) % 4:
+            # said at construction, not by a kernel in the middle of a backward pass: the row kernels work on 16-byte
+            # pieces of the hidden_dim / 4-wide layer, the attention kernels on 4-column pieces of a head
+            raise ValueError(f"the HIP edge head needs hidden_dim % 16 == 0 and a head width (hidden_dim / num_heads) % 4 == 0 "
+                             f"(got hidden_dim={hidden_dim}, num_heads={num_heads})")
         h = hidden_dim
         self.vertex_proj = nn.Sequential(
             nn.Linear(vertex_dim, h // 2), nn.LayerNorm(h // 2), nn.GELU(),
