@@ -729,3 +729,11 @@ def test_edge_head_sizes_outside_the_kernels_granularity_are_refused_at_construc
     from models.EdgePredictor import EdgePredictor
     with pytest.raises(ValueError, match="hidden_dim"):
         EdgePredictor(3, hidden, heads)
+
+
+@pytest.mark.parametrize("hidden,out", [([30, 50], 22), ([33], 18), ([6], 2), ([512, 8192], 64), ([64], 17)])
+def test_encoder_sizes_outside_the_kernels_granularity_are_refused_at_construction(hidden, out):
+    from models.PointNetEncoder import PointNetEncoder
+    with pytest.raises(ValueError, match="hidden"):
+        PointNetEncoder(8, hidden, out)
+    PointNetEncoder(8, [36, 20], 12)                  # multiples of 4 / even: fine

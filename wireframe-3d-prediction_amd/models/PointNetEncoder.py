@@ -18,6 +18,12 @@ def _point_block(n_in, n_out):
 class PointNetEncoder(nn.Module):
     def __init__(self, input_dim=8, hidden_dims=[512, 1024, 2048, 1024], output_dim=512):
         super().__init__()
+        bad = [h for h in hidden_dims if h % 4 or not 0 < h <= 4096]
+        if bad or output_dim % 2 or output_dim <= 0:
+            # said here, not by a kernel in the middle of a backward pass: LayerNorm rows are handled in 16-byte pieces
+            # (hidden widths, and the fusion MLP's 4 x / 2 x output_dim) and kept in registers up to 4096 columns
+            raise ValueError(f"the HIP encoder needs hidden widths that are multiples of 4 (<= 4096) and an even output_dim "
+                             f"(got hidden_dims={list(hidden_dims)}, output_dim={output_dim})")
         widths = [input_dim] + list(hidden_dims)
         stack = []
         for n_in, n_out in zip(widths[:-1], widths[1:]):
