@@ -189,3 +189,18 @@ def test_persistent_kernel_on_fewer_workgroups(cus):
     finally:
         lib.wf3d_set_option(b"gemm_cus", 0)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M,K,N", [(131072, 256, 256), (131072, 320, 256), (65536, 384, 512), (33024, 4096, 1024), (32768, 256, 4096),
+                                   (131072, 192, 256), (16640, 2048, 2048)])
+def test_persistent_kernel_at_the_edges_of_its_selection(ops, M, K, N):
+    """Reductions of exactly 8 slices (the tile-claim protocol's minimum: draw at slice 0, consumed at slice 3, needed
+    before the last two), odd multiples of 32 and fewer than 8 slices (the plain kernel takes those), a row count that
+    leaves workgroups without a tile in the last round, a 16-column-tile panel, and just above the 2-tiles-per-CU
+    threshold — every output element against fp64."""
+    A, W, bias = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.05), rnd(N, seed=13)
+    As, Ws = ops.split_rows(A), ops.split_rows(W)
+    got = ops.gemm_split(As, Ws, bias=bias)
+    r, _ = worst_nt(got, A, W, bias)
+    assert r < TOL_SPLIT, f"M={M} K={K} N={N}: {r:.2e}"
+    assert torch.equal(got, ops.gemm_split(As, Ws, bias=bias, out=torch.full_like(got, -3.0)))
