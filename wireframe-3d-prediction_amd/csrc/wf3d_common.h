@@ -52,24 +52,30 @@ static inline int wf3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers --------------------------------------------------------
 #ifdef __HIPCC__
-// erf from e = exp(-a^2): 1 - (a1 t + ... + a5 t^5) e with t = 1 / (1 + p |a|) (Abramowitz & Stegun 7.1.26, absolute error
-// <= 1.5e-7 — the GELU values and derivatives it feeds are held to 1e-4 of their tensors' scale).  13 VALU issue slots
-// counting the reciprocal as 4, against 26 for the 1-ulp two-piece minimax form used until round 3, and the exponential is
-// the one the Gaussian density of GELU's derivative needs anyway: at max_vertices = 256 the pair kernel and the LayerNorm
-// backward of the first edge layer are bound by these instructions, not by HBM.
-__device__ __forceinline__ float wf3d_exp_neg_sq(float a) {            // exp(-a^2): one multiply, one v_exp_f32
-    return __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
+// erf in fp32 to ~1 ulp, branch-free: both polynomial pieces (N. Juffa's minimax coefficients: |x| <= 0.9277 odd
+// polynomial in x; beyond, 1 - exp(-|x| * P(|x|))) are evaluated and selected — 21 VALU operations against the ~42 of
+// the library erff, whose two paths a wave with mixed arguments both walks anyway.  The edge head evaluates GELU or its
+// derivative on every element of its [edges, 512 / 256 / 128] activations: at max_vertices = 256 the pair kernel and
+// the LayerNorm backward of the first edge layer are bound by these instructions, not by HBM.
+__device__ __forceinline__ float wf3d_erf(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
 }
-__device__ __forceinline__ float wf3d_erf_e(float a, float e) {
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(a), 1.0f));
-    float p = 1.061405429f;
-    p = fmaf(p, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    return copysignf(fmaf(-p * t, e, 1.0f), a);
-}
-__device__ __forceinline__ float wf3d_erf(float a) { return wf3d_erf_e(a, wf3d_exp_neg_sq(a)); }
 
 // activations used on the path: ReLU (encoder / vertex head), erf-GELU (edge head)
 template <int ACT>
@@ -83,10 +89,9 @@ template <int ACT>
 __device__ __forceinline__ float wf3d_act_grad(float y) {
     if (ACT == WF3D_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
     if (ACT == WF3D_ACT_GELU) {
-        const float x = y * 0.70710678118654752440f;
-        const float e = wf3d_exp_neg_sq(x);                        // exp(-y^2 / 2): shared by the distribution and its density
-        const float cdf = fmaf(0.5f, wf3d_erf_e(x, e), 0.5f);
-        return fmaf(y * 0.39894228040143267794f, e, cdf);
+        const float cdf = 0.5f * (1.0f + wf3d_erf(y * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * y * y);
+        return cdf + y * pdf;
     }
     return 1.0f;
 }
