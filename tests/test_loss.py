@@ -141,3 +141,41 @@ def test_train_meter_tracks_the_reference_loop_quantities_without_syncs():
     assert abs(m["vertex_rmse"] - rmse) < 1e-6 and abs(m["total_loss"] - hist[-1]) < 1e-7
     assert abs(m["edge_loss"] - float(losses["edge_loss"])) < 1e-7
     assert np.allclose(m["loss_history"], hist[-4:], atol=1e-7)          # ring of the last `history` steps, oldest first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,V,counts,ep,et", [(1, 1, [1], 1, 1), (1, 2, [0], 1, 1), (2, 3, [0, 0], 3, 3), (5, 4, [4, 1, 0, 2, 3], 6, 4),
+                                              (64, 3, None, 3, 3), (3, 130, [130, 1, 77], 400, 8385), (2, 256, [256, 200], 32640, 32640),
+                                              (7, 17, None, 136, 50)])
+def test_device_loss_matches_the_cpu_oracle_at_other_shapes(B, V, counts, ep, et):
+    """Losses, assignment and input gradients against oracle/loss_cpu.py (pinned by the reference's fixtures above) at shapes the
+    fixtures do not hold: single samples and vertices, batches without any target vertex, 64 samples, 130 / 256 vertices, edge
+    widths that differ between prediction and target in either direction."""
+    from losses.WireframeLoss import WireframeLoss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + V)
+    if counts is None:
+        counts = torch.randint(0, V + 1, (B,), generator=g).tolist()
+    cnt = torch.tensor(counts, dtype=torch.long)
+    pv, tv = torch.randn(B, V, 3, generator=g), torch.randn(B, V, 3, generator=g)
+    pe = torch.sigmoid(2.0 * torch.randn(B, V, generator=g))
+    pp = torch.sigmoid(2.0 * torch.randn(B, ep, generator=g))
+    tl = (torch.rand(B, et, generator=g) > 0.7).float()
+    te = (torch.arange(V)[None, :] < cnt[:, None]).float()
+    tg = {"vertices": tv, "vertex_existence": te, "edge_labels": tl, "vertex_counts": cnt}
+    pc = {"vertices": pv.clone().requires_grad_(), "existence_probabilities": pe.clone().requires_grad_(), "edge_probs": pp.clone().requires_grad_()}
+    ref, ref_m = loss_cpu.wireframe_loss(pc, tg, 3.0, 1.5, 1.0)
+    ref["total_loss"].backward()
+    pd = {k: v.detach().clone().to(dev).requires_grad_() for k, v in pc.items()}
+    crit = WireframeLoss(3.0, 1.5, 1.0)
+    out = crit(pd, {k: v.to(dev) for k, v in tg.items()})
+    for k in ("total_loss", "vertex_loss", "existence_loss", "edge_loss"):
+        assert abs(float(out[k]) - float(ref[k])) < 5e-6 * max(1.0, abs(float(ref[k]))), (k, float(out[k]), float(ref[k]))
+    out["total_loss"].backward()
+    for k in pc:
+        a, b = pd[k].grad, pc[k].grad
+        if b is None:                                   # e.g. no target vertex anywhere: the vertex term does not depend on the coordinates
+            assert a is None or float(a.abs().max()) == 0.0, k
+            continue
+        assert a is not None, k
+        assert float((a.cpu() - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-12), k
