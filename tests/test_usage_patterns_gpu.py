@@ -126,3 +126,18 @@ def test_deepcopy_state_dict_and_tensor_hooks(setup):
     finally:
         h.remove()
     assert _close(m.encoder.mlp[4].weight.grad, 2 * ref["encoder.mlp.4.weight"])
+
+
+def test_forward_and_backward_on_a_non_default_stream(setup):
+    """Everything is queued on the caller's current stream (scratch buffers, the edge head's side-stream leaves and the
+    persistent GEMM's claim counters are per stream): a step under another stream gives the same gradients."""
+    m, x, c, ref = setup
+    s = torch.cuda.Stream(x.device)
+    s.wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(s):
+        m.zero_grad()
+        _loss(m(x, c)).backward()
+    s.synchronize()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert _close(p.grad, ref[n]), n
