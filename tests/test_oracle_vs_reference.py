@@ -54,3 +54,82 @@ def test_oracle_matches_imported_reference():
                        capture_output=True, text=True, timeout=600,
                        env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
     assert "ORACLE_MATCHES_REFERENCE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+SIZES_SCRIPT = r"""
+import sys
+sys.dont_write_bytecode = True
+sys.path.insert(0, %(ref)r); sys.path.insert(0, %(root)r)
+import torch
+from models.PointNetEncoder import PointNetEncoder          # the reference's classes
+from models.EdgePredictor import EdgePredictor
+from models.VertexPredictor import VertexPredictor
+from oracle import reference_cpu as oracle
+
+def quiet(m):
+    for s in m.modules():
+        if isinstance(s, torch.nn.Dropout): s.p = 0.0
+        if isinstance(s, torch.nn.MultiheadAttention): s.dropout = 0.0
+    return m.train()
+
+def same(a, b, tol, what):
+    d = (a - b).abs().max().item(); s = max(a.abs().max().item(), 1e-30)
+    assert d <= tol * s, (what, d, s)
+
+def grads(m, P, prefix, what):
+    for n, p in m.named_parameters():
+        r = P[prefix + n].grad
+        if p.grad is None:
+            assert r is None, (what, n)
+        else:
+            same(p.grad, r, 2e-5, (what, n))
+
+torch.manual_seed(1)
+for hidden, out in (([256, 768], 768), ([264, 520], 264), ([], 40), ([64, 128, 256, 128, 64], 32), ([512], 96)):
+    m = quiet(PointNetEncoder(8, hidden, out))
+    x = torch.randn(3, 70, 8); x[:, ::9] = 0
+    g, pf = m(x)
+    P = {"encoder." + k: v for k, v in oracle.params_from_module(m).items()}
+    g2, pf2 = oracle.encoder_forward(P, x)
+    same(g, g2, 2e-6, ("enc g", hidden, out)); same(pf, pf2, 2e-6, ("enc pf", hidden, out))
+    cg, cp = torch.randn_like(g), torch.randn_like(pf)
+    ((g * cg).sum() + (pf * cp).sum()).backward(); ((g2 * cg).sum() + (pf2 * cp).sum()).backward()
+    grads(m, P, "encoder.", ("enc", hidden, out))
+for vd, hidden, heads, cnt in ((3, 208, 4, 6), (6, 96, 3, 8), (3, 1024, 16, 5), (2, 128, 8, 9), (3, 384, 6, 4)):
+    m = quiet(EdgePredictor(vd, hidden, heads))
+    v = torch.randn(1, cnt, vd, requires_grad=True)
+    probs, idx = m(v)
+    P = {"edge_predictor." + k: t for k, t in oracle.params_from_module(m).items()}
+    v2 = v.detach().clone().requires_grad_()
+    p2, idx2 = oracle.edge_forward(P, v2, num_heads=heads)
+    same(probs, p2, 2e-6, ("edge", hidden, heads))
+    c = torch.randn_like(probs)
+    (probs * c).sum().backward(); (p2 * c).sum().backward()
+    same(v.grad, v2.grad, 2e-5, ("edge dv", hidden, heads))
+    grads(m, P, "edge_predictor.", ("edge", hidden, heads))
+for gdim, V in ((384, 10), (200, 7), (64, 40), (1024, 12)):
+    m = quiet(VertexPredictor(gdim, V, 4))
+    g = torch.randn(3, gdim, requires_grad=True); pf = torch.randn(3, 9, gdim, requires_grad=True)
+    o = m(g, pf)                                  # creates the lazy point_pool_proj
+    P = {"vertex_predictor." + k: t for k, t in oracle.params_from_module(m).items()}
+    g2, pf2 = g.detach().clone().requires_grad_(), pf.detach().clone().requires_grad_()
+    o2 = oracle.vertex_forward(P, g2, pf2, V, 4)
+    same(o["vertices"], o2["vertices"], 2e-6, ("vert", gdim, V)); same(o["existence_probabilities"], o2["existence_probabilities"], 2e-6, ("exist", gdim, V))
+    assert torch.equal(o["actual_vertex_counts"], o2["actual_vertex_counts"])
+    cv, ce = torch.randn_like(o["vertices"]), torch.randn_like(o["existence_probabilities"])
+    ((o["vertices"] * cv).sum() + (o["existence_probabilities"] * ce).sum()).backward()
+    ((o2["vertices"] * cv).sum() + (o2["existence_probabilities"] * ce).sum()).backward()
+    same(g.grad, g2.grad, 2e-5, ("vert dg", gdim)); same(pf.grad, pf2.grad, 2e-5, ("vert dpf", gdim))
+    grads(m, P, "vertex_predictor.", ("vert", gdim, V))
+print("ORACLE_MATCHES_REFERENCE_AT_OTHER_SIZES")
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), reason="reference not present")
+def test_oracle_matches_imported_reference_at_other_constructor_sizes():
+    """The size sweeps of tests/test_model_gpu.py compare the kernels with the oracle at widths, depths, head counts and
+    vertex counts that are not the model's: here the oracle itself is held to the reference's classes at those sizes."""
+    r = subprocess.run([sys.executable, "-c", SIZES_SCRIPT % {"ref": REF, "root": ROOT}],
+                       capture_output=True, text=True, timeout=900,
+                       env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert "ORACLE_MATCHES_REFERENCE_AT_OTHER_SIZES" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
